@@ -1,0 +1,270 @@
+"""Generate tests/golden/*.npz by running the REAL reference (build container only).
+
+    MPLBACKEND=Agg python oracle/make_golden.py
+
+Imports /root/reference/01_train_pinn_multiphysics_model.py as a module (its `__main__`
+guard keeps the import side-effect free) and applies ONE shim to the imported module
+object: `StepLR(..., verbose=False)` (01:940) is rejected by torch 2.10, so `ref01.StepLR`
+is wrapped to drop that kwarg.  Nothing of the reference is copied: the committed
+fixtures hold synthetic inputs and the reference's numeric outputs only.
+
+Fixture index:
+  g_net128.npz   G1/G2/G3/G4  weights of an [8,128,128,128,1] net, eval forward, stochastic
+                              forwards with hooked masks (bit-packed), NLL loss + 14 grads
+  g_net256.npz   G2/G3        same for the reference architecture [8,256,256,256,1] (forward only)
+  g_resid.npz    G5           every tuple element of net_f_V / _T_simple / _H / _O / _T on rows that
+                              hit each branch edge, + d mean(f^2)/d lambda, at two lambda sets
+  g_traj.npz     G6           lambda trajectories of the five physics stages + lr across a StepLR edge
+  g_train.npz    G7           weights after 3 train_dnn steps with the masks the reference drew
+  g_mc.npz       G8           get_MC_samples outputs with recorded masks (T=4)
+  g_results.npz  G9           the [N,22] comprehensive_results array for 300+150+250 rows
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pinn_amd  # noqa: E402  (product package: only its numpy synthetic-data generator is used)
+from pinn_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference/01_train_pinn_multiphysics_model.py"
+
+
+def load_reference():
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    spec = importlib.util.spec_from_file_location("ref01", REF)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    _StepLR = torch.optim.lr_scheduler.StepLR
+    ref.StepLR = lambda opt, **kw: _StepLR(opt, **{k: v for k, v in kw.items() if k != "verbose"})
+    return ref
+
+
+class MaskRecorder:
+    """Forward hooks on the four nn.Dropout modules; records `out != 0` while training."""
+
+    def __init__(self, dnn):
+        self.mods = [m for _, m in dnn.named_modules() if isinstance(m, torch.nn.Dropout)]
+        self.calls = []          # list over forwards of list over modules of bool arrays
+        self._cur = []
+        for m in self.mods:
+            m.register_forward_hook(self._hook)
+
+    def _hook(self, mod, inp, out):
+        if not mod.training:
+            return
+        self._cur.append((out != 0).numpy().copy())
+        if len(self._cur) == len(self.mods):
+            self.calls.append(self._cur)
+            self._cur = []
+
+    def reset(self):
+        self.calls, self._cur = [], []
+
+
+def pack(mask):
+    return np.packbits(np.asarray(mask, dtype=np.uint8), axis=-1, bitorder="little")
+
+
+def state(dnn):
+    sd = dnn.state_dict()
+    return {k: v.detach().numpy().copy() for k, v in sd.items() if not k.startswith("lambda")}
+
+
+def scaler_arrays(prefix, sc):
+    return {prefix + "min_": np.asarray(sc.min_, np.float64), prefix + "scale_": np.asarray(sc.scale_, np.float64),
+            prefix + "data_min_": np.asarray(sc.data_min_, np.float64), prefix + "data_max_": np.asarray(sc.data_max_, np.float64)}
+
+
+def edge_rows(ds, lamH3=197.715, lamO3=200.0):
+    """256 normalised rows whose de-normalised values sit on every branch edge of A6/A7."""
+    x_train, y_train, _, _, sx, sy, _ = ds
+    X = np.asarray(sx.inverse_transform(x_train.numpy().astype(np.float64)))[:256].copy()
+    Y = np.asarray(sy.inverse_transform(y_train.numpy().astype(np.float64)))[:256].copy()
+    # It = 270*(I/270+1e-5): put rows at / around the hydrogen and oxygen thresholds
+    for k, tgt in enumerate([lamH3, np.nextafter(np.float32(lamH3), np.float32(1e9)), np.nextafter(np.float32(lamH3), np.float32(0)),
+                             lamO3, 230.0, 210.0, 199.99, 200.01]):
+        X[k, 0] = float(tgt) - 270e-5
+    # oxygen target clamps: high I*lambda_O2 pushes raw above 15 with the second lambda set
+    X[8:12, 0] = [404.0, 380.0, 60.0, 55.0]
+    # act_O < 1 penalty rows: starve the air flow
+    X[12:20, 7] *= 0.3
+    # act_H far from target
+    X[20:24, 6] *= 0.5
+    xn = sx.transform(X).astype(np.float32)
+    yn = sy.transform(Y).astype(np.float32)
+    return torch.from_numpy(xn), torch.from_numpy(yn)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = load_reference()
+    ds = synth.make_dataset(1024, (), seed=0)
+    x_train, y_train, _, _, sx, sy, _ = ds
+    x256, y256 = x_train[:256].clone(), y_train[:256].clone()
+
+    # ------------------------------------------------------------------ G1-G4 (net128), G2/G3 (net256)
+    for H, fname in ((128, "g_net128.npz"), (256, "g_net256.npz")):
+        torch.manual_seed(100 + H)
+        m = ref.PhysicsInformedNN(x256, y256, [8, H, H, H, 1], sx, sy, p=0.2, logvar=True)
+        out = {"x": x256.numpy(), "y": y256.numpy()}
+        out.update({"w." + k: v for k, v in state(m.dnn).items()})
+        m.dnn.eval()
+        with torch.no_grad():
+            u, lv = m.net_u(m.x)
+        out["eval_u"], out["eval_logvar"] = u.numpy(), lv.numpy()
+        rec = MaskRecorder(m.dnn)
+        for p in (0.2, 0.4):
+            for mod in rec.mods:
+                mod.p = p
+            m.dnn.train()
+            for t in range(2):
+                rec.reset()
+                if H == 128 and p == 0.2 and t == 0:
+                    for prm in m.dnn.parameters():
+                        prm.requires_grad = True
+                    u, lv = m.net_u(m.x)
+                    loss = m.aleatoric_loss(m.u, u, lv)
+                    m.dnn.zero_grad()
+                    loss.backward()
+                    out["loss_p0.2_t0"] = np.float64(loss.item())
+                    for k, prm in m.dnn.named_parameters():
+                        if not k.startswith("lambda"):
+                            out["grad." + k] = prm.grad.numpy().copy()
+                else:
+                    with torch.no_grad():
+                        u, lv = m.net_u(m.x)
+                tag = "p%.1f_t%d" % (p, t)
+                out["sto_u_" + tag], out["sto_logvar_" + tag] = u.detach().numpy(), lv.detach().numpy()
+                for li, mk in enumerate(rec.calls[0]):
+                    out["mask%d_%s" % (li, tag)] = pack(mk)
+        np.savez_compressed(os.path.join(OUT, fname), **out)
+        print(fname, "ok")
+
+    # ------------------------------------------------------------------ G5 residuals
+    xe, ye = edge_rows(ds)
+    torch.manual_seed(7)
+    m = ref.PhysicsInformedNN(xe, ye, [8, 128, 128, 128, 1], sx, sy, p=0.2, logvar=True)
+    m.dnn.eval()
+    out = {"x": xe.numpy(), "y": ye.numpy()}
+    out.update(scaler_arrays("sx.", sx)); out.update(scaler_arrays("sy.", sy))
+    with torch.no_grad():
+        out["u_eval"] = m.net_u(m.x)[0].numpy()
+    lam_sets = [dict(), dict(lambda_1=0.25, lambda_2=1.1e-6, lambda_3=3.3, lambda_T1=0.02, lambda_T3=-0.11, lambda_T5=31.0,
+                             lambda_H1=1.9, lambda_H2=0.31, lambda_H3=230.0, lambda_O1=0.9, lambda_O2=3.9, lambda_O3=-210.0)]
+    names = ["lambda_1", "lambda_2", "lambda_3", "lambda_4", "lambda_T1", "lambda_T2", "lambda_T3", "lambda_T4", "lambda_T5",
+             "lambda_H1", "lambda_H2", "lambda_H3", "lambda_H4", "lambda_O1", "lambda_O2", "lambda_O3", "lambda_O4"]
+    for si, ls in enumerate(lam_sets):
+        for k, v in ls.items():
+            getattr(m, k).data.fill_(v)
+        out["s%d.lambdas" % si] = np.array([getattr(m, n).item() for n in names], np.float64)
+        for n in names:
+            getattr(m, n).requires_grad_(True)
+        for fn, tag, keep in ((m.net_f_V, "V", 9), (m.net_f_T_simple, "T", 3), (m.net_f_H, "H", 4), (m.net_f_O, "O", 5), (m.net_f_T, "TE", 3)):
+            res = fn(xe, sx)
+            for j in range(keep):
+                r = res[j]
+                out["s%d.%s.%d" % (si, tag, j)] = r.detach().numpy().copy()
+            if tag != "TE":
+                loss = torch.mean(res[0] ** 2)
+                gs = torch.autograd.grad(loss, [getattr(m, n) for n in names], allow_unused=True)
+                out["s%d.%s.loss" % (si, tag)] = np.float64(loss.item())
+                out["s%d.%s.grad" % (si, tag)] = np.array([0.0 if g is None else g.item() for g in gs], np.float64)
+                out["s%d.%s.grad_none" % (si, tag)] = np.array([g is None for g in gs])
+        # train_lambda(dnn_para=False) loss: mean((y - V_est_norm)^2), 01:1017-1032
+        res = m.net_f_V(xe, sx)
+        lo, hi = -1.0, 1.0
+        dmin = torch.tensor(sy.data_min_, dtype=torch.float32); dmax = torch.tensor(sy.data_max_, dtype=torch.float32)
+        scale_y = (hi - lo) / (dmax - dmin + 1e-12); min_y = lo - dmin * scale_y
+        loss = torch.mean((m.u - (res[5] * scale_y + min_y)) ** 2)
+        gs = torch.autograd.grad(loss, [getattr(m, n) for n in names], allow_unused=True)
+        out["s%d.Vn.loss" % si] = np.float64(loss.item())
+        out["s%d.Vn.grad" % si] = np.array([0.0 if g is None else g.item() for g in gs], np.float64)
+    np.savez_compressed(os.path.join(OUT, "g_resid.npz"), **out)
+    print("g_resid.npz ok")
+
+    # ------------------------------------------------------------------ G6 trajectories
+    out = {}
+    x64, y64 = x_train[:64].clone(), y_train[:64].clone()
+    out["x"], out["y"] = x64.numpy(), y64.numpy()
+    out.update(scaler_arrays("sx.", sx)); out.update(scaler_arrays("sy.", sy))
+    torch.manual_seed(11)
+    m0 = ref.PhysicsInformedNN(x64, y64, [8, 128, 128, 128, 1], sx, sy, p=0.2, logvar=True)
+    out.update({"w." + k: v for k, v in state(m0.dnn).items()})
+    m0.dnn.eval()
+    with torch.no_grad():
+        out["u_eval"] = m0.net_u(m0.x)[0].numpy()
+    stage_calls = {"lambdaF": lambda mm, k: mm.train_lambda(k, False), "lambdaT": lambda mm, k: mm.train_lambda(k, True),
+                   "thermal": lambda mm, k: mm.train_thermal(k), "hydrogen": lambda mm, k: mm.train_hydrogen(k),
+                   "oxygen": lambda mm, k: mm.train_oxygen(k)}
+    import contextlib, io
+    for sname, call in stage_calls.items():
+        for k in (1, 2, 5, 50, 1003):
+            if k == 1003 and sname not in ("thermal", "lambdaF"):
+                continue
+            torch.manual_seed(11)
+            mm = ref.PhysicsInformedNN(x64, y64, [8, 128, 128, 128, 1], sx, sy, p=0.2, logvar=True)
+            with contextlib.redirect_stdout(io.StringIO()):
+                call(mm, k)
+            out["%s.k%d" % (sname, k)] = np.array([getattr(mm, n).item() for n in names], np.float64)
+    np.savez_compressed(os.path.join(OUT, "g_traj.npz"), **out)
+    print("g_traj.npz ok")
+
+    # ------------------------------------------------------------------ G7 train_dnn with recorded masks
+    torch.manual_seed(21)
+    m = ref.PhysicsInformedNN(x256, y256, [8, 128, 128, 128, 1], sx, sy, p=0.2, logvar=True)
+    out = {"x": x256.numpy(), "y": y256.numpy()}
+    out.update({"w0." + k: v for k, v in state(m.dnn).items()})
+    rec = MaskRecorder(m.dnn)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m.train_dnn(3)
+    assert len(rec.calls) == 3
+    for s, call in enumerate(rec.calls):
+        for li, mk in enumerate(call):
+            out["mask%d_s%d" % (li, s)] = pack(mk)
+    out.update({"w3." + k: v for k, v in state(m.dnn).items()})
+    np.savez_compressed(os.path.join(OUT, "g_train.npz"), **out)
+    print("g_train.npz ok")
+
+    # ------------------------------------------------------------------ G8 MC-dropout with recorded masks
+    torch.manual_seed(31)
+    m = ref.PhysicsInformedNN(x256, y256, [8, 128, 128, 128, 1], sx, sy, p=0.2, logvar=True)
+    out = {"x": x256.numpy()}
+    out.update({"w." + k: v for k, v in state(m.dnn).items()})
+    rec = MaskRecorder(m.dnn)
+    with contextlib.redirect_stdout(io.StringIO()):
+        pm, au, eu = ref.get_MC_samples(m, x256, sx, mc_times=4, dropout=0.4)
+    # each stochastic predict() runs the DNN twice (01:1406 and, discarded, 01:1407 -> 01:733)
+    assert len(rec.calls) == 8
+    for t in range(4):
+        for li, mk in enumerate(rec.calls[2 * t]):
+            out["mask%d_t%d" % (li, t)] = pack(mk)
+    out["pred_mean"], out["a_u"], out["e_u"] = pm, au, eu
+    np.savez_compressed(os.path.join(OUT, "g_mc.npz"), **out)
+    print("g_mc.npz ok")
+
+    # ------------------------------------------------------------------ G9 results array
+    ds9 = synth.make_dataset(300, (150, 250), seed=3)
+    torch.manual_seed(41)
+    m = ref.PhysicsInformedNN(ds9[0], ds9[1], [8, 128, 128, 128, 1], ds9[4], ds9[5], p=0.2, logvar=True)
+    rec = MaskRecorder(m.dnn)
+    with contextlib.redirect_stdout(io.StringIO()):
+        arr = ref.create_comprehensive_results_array_v2(m, ds9, mc_times=3, dropout=0.4)
+    assert len(rec.calls) == 6
+    out = {"results": arr, "x_test": ds9[2].numpy(), "y_test": ds9[3].numpy(), "boundary_lines": np.array(ds9[6]["boundary_lines"])}
+    out.update(scaler_arrays("sx.", ds9[4])); out.update(scaler_arrays("sy.", ds9[5]))
+    out.update({"w." + k: v for k, v in state(m.dnn).items()})
+    for t in range(3):
+        for li, mk in enumerate(rec.calls[2 * t]):
+            out["mask%d_t%d" % (li, t)] = pack(mk)
+    np.savez_compressed(os.path.join(OUT, "g_results.npz"), **out)
+    print("g_results.npz ok")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,486 @@
+"""CPU oracle for the PINN training + MC-dropout hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, op for op in float32, the arithmetic of the reference's
+`01_train_pinn_multiphysics_model.py` (cited below as 01:<line>) on torch-CPU / numpy.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import
+it, as the checker -- never the product package.  The product path is the HIP library
+behind include/pinn_hip.h and fails loudly when that library is missing.
+
+Pinning: `oracle/make_golden.py` imports the real reference in the build container and
+writes `tests/golden/*.npz`; `tests/test_oracle_golden.py` checks every function here
+against those vectors (no golden vectors ship with the reference itself).
+
+The two places this oracle goes beyond the reference are both needed to check the HIP
+path deterministically:
+  * dropout takes explicit keep-masks (the reference draws them from torch's unseeded
+    CPU generator, 01:404/415); `philox_keep_mask` is the specification of the on-chip
+    counter-based masks the kernels generate;
+  * sklearn's `inverse_transform` host round trips (01:542, 629, 726, 735, 879) are
+    replaced by the same two float64-against-float32 affine steps (`denorm`).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------------------
+# Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11) --
+# the published algorithm; pinned by the Random123 known-answer vectors in the tests.
+# ----------------------------------------------------------------------------------------
+_PHILOX_M0 = np.uint64(0xD2511F53)
+_PHILOX_M1 = np.uint64(0xCD9E8D57)
+_PHILOX_W0 = 0x9E3779B9
+_PHILOX_W1 = 0xBB67AE85
+_MASK32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10. Counter words / key words: uint32 arrays (broadcastable)."""
+    c0, c1, c2, c3 = [np.asarray(c, dtype=np.uint64) & _MASK32 for c in (c0, c1, c2, c3)]
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 = int(k0) & 0xFFFFFFFF
+    k1 = int(k1) & 0xFFFFFFFF
+    for r in range(10):
+        p0 = _PHILOX_M0 * c0
+        p1 = _PHILOX_M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & _MASK32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & _MASK32
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ np.uint64(k0)), lo1, (hi0 ^ c3 ^ np.uint64(k1)), lo0
+        k0 = (k0 + _PHILOX_W0) & 0xFFFFFFFF
+        k1 = (k1 + _PHILOX_W1) & 0xFFFFFFFF
+    return [c.astype(np.uint32) for c in (c0, c1, c2, c3)]
+
+
+def dropout_threshold16(p):
+    """16-bit drop threshold: element kept iff its 16-bit draw >= thr. P(keep) = 1 - thr/65536."""
+    return int(min(65536, max(0, math.floor(float(p) * 65536.0 + 0.5))))
+
+
+def philox_keep_mask(seed, stream, row0, n_rows, layer_id, width, p):
+    """Keep-mask [n_rows, width] (bool) of one dropout layer -- the on-chip mask specification.
+
+    One Philox call yields eight 16-bit draws.  For feature f of dropout layer `layer_id`
+    (0-based over the net's Dropout modules) and GLOBAL row index g = row0 + r:
+        counter = (g & 0xffffffff, g >> 32, layer_id << 16 | call, stream),  key = (seed lo, hi)
+        call = (f >> 5) << 2 | ((f >> 2) & 1) << 1 | ((f >> 4) & 1)
+        word = 2 * ((f >> 3) & 1) + ((f >> 1) & 1),   half = f & 1  (0 = low 16 bits)
+    so a mask depends only on (seed, stream, global row, layer, feature): it is invariant
+    under any row -> GPU / workgroup / lane assignment.
+    `stream` is the optimizer step (training) or the pass index (MC-dropout).
+    """
+    thr = dropout_threshold16(p)
+    g = (np.arange(n_rows, dtype=np.uint64) + np.uint64(row0))[:, None]
+    f = np.arange(width, dtype=np.uint64)[None, :]
+    call = ((f >> np.uint64(5)) << np.uint64(2)) | (((f >> np.uint64(2)) & np.uint64(1)) << np.uint64(1)) \
+        | ((f >> np.uint64(4)) & np.uint64(1))
+    word = (np.uint64(2) * ((f >> np.uint64(3)) & np.uint64(1)) + ((f >> np.uint64(1)) & np.uint64(1))).astype(np.int64)
+    half = (f & np.uint64(1)).astype(np.int64)
+    c2 = (np.uint64(layer_id) << np.uint64(16)) | call
+    out = philox4x32_10(g & _MASK32, g >> np.uint64(32), c2, np.uint64(int(stream) & 0xFFFFFFFF),
+                        int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
+    words = np.stack(out, axis=0)                                    # [4, n_rows, width]
+    word_b = np.broadcast_to(word, (n_rows, width))
+    sel = np.take_along_axis(words, word_b[None, :, :], axis=0)[0]
+    draw = (sel >> (np.uint32(16) * half.astype(np.uint32))) & np.uint32(0xFFFF)
+    return draw >= np.uint32(thr) if thr < 65536 else np.zeros((n_rows, width), dtype=bool)
+
+
+def philox_masks_for_net(seed, stream, row0, n_rows, hidden, n_hidden, p_list):
+    """Keep-masks of all dropout modules in forward order: hidden layers 0..n_hidden-1
+    (`layers.dropout_i`, 01:404) then the variance head's single dropout (`var_layers.2`, 01:415)."""
+    widths = [hidden] * n_hidden + [hidden // 2]
+    return [philox_keep_mask(seed, stream, row0, n_rows, l, w, p_list[l]) for l, w in enumerate(widths)]
+
+
+# ----------------------------------------------------------------------------------------
+# Affine (de)normalisation -- replaces sklearn MinMaxScaler round trips
+# ----------------------------------------------------------------------------------------
+def scaler_affine(scaler):
+    """(min_, scale_) float64 arrays of a MinMaxScaler-like object."""
+    return np.asarray(scaler.min_, dtype=np.float64).reshape(-1), np.asarray(scaler.scale_, dtype=np.float64).reshape(-1)
+
+
+def denorm(x_n, min_, scale_):
+    """sklearn `inverse_transform` on a float32 array (01:542/629/726/735/879):
+    `X -= min_; X /= scale_`, each against float64 operands, each rounded to float32."""
+    x = np.asarray(x_n, dtype=np.float32).astype(np.float64)
+    x = (x - min_).astype(np.float32).astype(np.float64)
+    x = (x / scale_).astype(np.float32)
+    return x
+
+
+def target_affine(u_scal):
+    """(scale_y, min_y) as `train_lambda` builds them in float32 (01:1017-1022)."""
+    lo, hi = float(u_scal.feature_range[0]), float(u_scal.feature_range[1])
+    dmin = torch.tensor(np.asarray(u_scal.data_min_), dtype=torch.float32)
+    dmax = torch.tensor(np.asarray(u_scal.data_max_), dtype=torch.float32)
+    scale_y = (hi - lo) / (dmax - dmin + 1e-12)
+    min_y = lo - dmin * scale_y
+    return scale_y, min_y
+
+
+# ----------------------------------------------------------------------------------------
+# DNN (01:389-438)
+# ----------------------------------------------------------------------------------------
+def param_names(n_hidden):
+    """state_dict order of the 2*(n_hidden+4) weight/bias tensors (01:399-419)."""
+    names = []
+    for i in range(n_hidden):
+        names += ["layers.layer_%d.weight" % i, "layers.layer_%d.bias" % i]
+    names += ["predict.weight", "predict.bias"]
+    for i in (0, 3, 5):
+        names += ["var_layers.%d.weight" % i, "var_layers.%d.bias" % i]
+    return names
+
+
+def init_params(layers, seed=0):
+    """torch-default Linear init of the reference architecture, as float32 tensors
+    in `param_names` order.  Mirrors the module construction order of 01:399-419 so
+    `torch.manual_seed(seed)` followed by `DNN(...)` in the reference gives the same numbers."""
+    g = torch.Generator().manual_seed(seed)
+    depth = len(layers) - 1
+    shapes = [(layers[i + 1], layers[i]) for i in range(depth - 1)]
+    H = layers[-2]
+    shapes += [(layers[-1], H), (H // 2, H), (H // 4, H // 2), (layers[-1], H // 4)]
+    out = []
+    for (o, i) in shapes:
+        bound = 1.0 / math.sqrt(i)
+        # kaiming_uniform_(a=sqrt(5)) on [o, i] == U(-1/sqrt(i), 1/sqrt(i)); bias: same bound
+        w = (torch.rand(o, i, generator=g) * 2 - 1) * bound
+        b = (torch.rand(o, generator=g) * 2 - 1) * bound
+        out += [w, b]
+    return out
+
+
+def dropout_scale(p):
+    """float32 factor torch applies to kept elements: noise.div_(1 - p) on a float32 mask."""
+    return np.float32(1.0) / np.float32(1.0 - float(p))
+
+
+def mlp_forward(params, x, p_list=None, masks=None):
+    """DNN.forward (01:421-438) with explicit keep-masks.
+
+    params: list of tensors in `param_names` order; x [N, n_in] float32 tensor.
+    masks: None (eval mode: dropout = identity) or list of n_hidden+1 bool/float arrays
+    ([N, H] per hidden layer, [N, H/2] for the variance head); p_list the matching p's.
+    Returns (u [N,1], logvar [N,1]).
+    """
+    n_hidden = (len(params) - 8) // 2
+    h = x
+    for l in range(n_hidden):
+        a = torch.tanh(F.linear(h, params[2 * l], params[2 * l + 1]))
+        if masks is not None:
+            m = torch.as_tensor(np.asarray(masks[l]), dtype=torch.float32)
+            a = a * (m * float(dropout_scale(p_list[l])))
+        h = a
+    k = 2 * n_hidden
+    u = F.linear(h, params[k], params[k + 1])
+    v = torch.tanh(F.linear(h, params[k + 2], params[k + 3]))
+    if masks is not None:
+        m = torch.as_tensor(np.asarray(masks[n_hidden]), dtype=torch.float32)
+        v = v * (m * float(dropout_scale(p_list[n_hidden])))
+    v = torch.tanh(F.linear(v, params[k + 4], params[k + 5]))
+    z = F.linear(v, params[k + 6], params[k + 7])
+    logvar = torch.log(F.softplus(z) + 1e-6)
+    return u, logvar
+
+
+def aleatoric_loss(gt, pred_y, logvar):
+    """01:916-927."""
+    precision = torch.exp(-logvar)
+    loss = torch.mean(0.5 * precision * (gt - pred_y) ** 2 + 0.5 * logvar)
+    return loss + 0.01 * torch.mean(torch.abs(logvar))
+
+
+def nll_loss_and_grads(params, x, y, p_list=None, masks=None):
+    """One `train_dnn` forward/backward (01:949-953): loss value, mse and the gradient of
+    every weight/bias tensor, by autograd on the restated forward."""
+    ps = [p.detach().clone().requires_grad_(True) for p in params]
+    u, logvar = mlp_forward(ps, x, p_list, masks)
+    loss = aleatoric_loss(y, u, logvar)
+    grads = torch.autograd.grad(loss, ps)
+    mse = torch.mean((y - u) ** 2)
+    return loss.detach(), mse.detach(), [g.detach() for g in grads], u.detach(), logvar.detach()
+
+
+# ----------------------------------------------------------------------------------------
+# Adam + StepLR (+ clamp) exactly as torch.optim.Adam defaults are used at 01:939-955 etc.
+# ----------------------------------------------------------------------------------------
+class AdamState:
+    """Single-tensor torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay / amsgrad):
+    m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)."""
+
+    def __init__(self, params):
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
+        self.t = [0 for _ in params]
+
+    def step(self, params, grads, lr, b1=0.9, b2=0.999, eps=1e-8):
+        for i, (p, g) in enumerate(zip(params, grads)):
+            if g is None:           # torch skips parameters whose .grad is None
+                continue
+            self.t[i] += 1
+            t = self.t[i]
+            self.m[i].mul_(b1).add_(g, alpha=1 - b1)
+            self.v[i].mul_(b2).addcmul_(g, g, value=1 - b2)
+            bc1 = 1 - b1 ** t
+            bc2 = 1 - b2 ** t
+            step_size = lr / bc1
+            denom = (self.v[i].sqrt() / math.sqrt(bc2)).add_(eps)
+            p.addcdiv_(self.m[i], denom, value=-step_size)
+
+
+def steplr(lr0, gamma, step_size, epoch):
+    """lr used at 0-based epoch `epoch` under StepLR stepped once per epoch (01:955)."""
+    return lr0 * gamma ** (epoch // step_size)
+
+
+# ----------------------------------------------------------------------------------------
+# Physics residuals (01:535-914).  `real` = de-normalised rows [N, 8] float32 tensor.
+# lam: dict name -> 1-element float32 tensor (may require grad).
+# ----------------------------------------------------------------------------------------
+LAMBDA_INIT = {  # 01:453-456, 477-481, 497-500, 514-517
+    "lambda_1": 0.167897923477715, "lambda_2": 2.36682075851268e-06, "lambda_3": 2.43414469188443, "lambda_4": 1.0,
+    "lambda_T1": 10.0, "lambda_T2": 10.0, "lambda_T3": 10.0, "lambda_T4": 10.0, "lambda_T5": 10.0,
+    "lambda_H1": 5.0, "lambda_H2": -1.559, "lambda_H3": 197.715, "lambda_H4": 1.20,
+    "lambda_O1": 2.0, "lambda_O2": 0.5, "lambda_O3": 200.0, "lambda_O4": 1.0,
+}
+LAMBDA_NAMES = list(LAMBDA_INIT.keys())
+
+
+def init_lambdas(requires_grad=False):
+    return {k: torch.tensor([v], dtype=torch.float32, requires_grad=requires_grad) for k, v in LAMBDA_INIT.items()}
+
+
+def _t(v):
+    return torch.tensor([v], dtype=torch.float32)
+
+
+def net_f_V(real, u_norm, y_min, y_scale, lam):
+    """01:724-765. u_norm: DNN output (normalised), DETACHED as in the reference (01:734).
+    Returns the reference's 9-tuple."""
+    A_cell = _t(270)
+    i = real[:, 0:1] / A_cell + 1e-5
+    T_out = real[:, 5:6]
+    V_out = torch.from_numpy(denorm(u_norm.detach().numpy(), y_min, y_scale)) / _t(5)
+    r, io, il = lam["lambda_1"], lam["lambda_2"], lam["lambda_3"]
+    R, Fc, Tc = _t(8.314), _t(96485), _t(55)
+    P_H2 = real[:, 3:4] / 101 + 1
+    P_air = real[:, 4:5] / 101 + 1
+    Alpha, Gf_liq = _t(0.5), _t(-220170)
+    Tk = T_out + _t(273.15)
+    x = -2.1794 + 0.02953 * Tc - 9.1837e-5 * (Tc ** 2) + 1.4454e-7 * (Tc ** 3)
+    P_H2O = 10 ** x
+    pp_H2 = 0.5 * (P_H2 / (torch.exp(1.653 * i / (Tk ** 1.334))) - P_H2O)
+    pp_O2 = (P_air / torch.exp(4.192 * i / (Tk ** 1.334))) - P_H2O
+    b = R * Tk / (2. * Alpha * Fc)
+    V_act = -b * torch.log(i / io)
+    V_ohmic = -(i * r)
+    V_conc = Alpha * b * torch.log(1 - (i / il))
+    E_nerst = -Gf_liq / (2 * Fc) - ((R * Tk) * torch.log(P_H2O / (pp_H2 * (pp_O2 ** 0.5)))) / (2 * Fc)
+    V_out_est = E_nerst + V_act + V_ohmic + V_conc
+    f = V_out_est - V_out
+    return f, V_act, V_ohmic, V_conc, E_nerst, V_out_est * 5, i, il, V_out * 5
+
+
+def net_f_T_simple(real, lam):
+    """01:869-914 (the DNN forward at 01:873-877 is dead code there and omitted)."""
+    A_cell = torch.tensor(270.0)
+    i = real[:, 0:1] / A_cell + 1e-6
+    m_coolant = real[:, 1:2] + 1e-6
+    T_in = real[:, 2:3]
+    T_out_real = real[:, 5:6]
+    I_total = i * A_cell
+    T_pred = lam["lambda_T1"] * I_total + lam["lambda_T3"] * m_coolant + 0.5 * T_in + lam["lambda_T5"]
+    return T_out_real - T_pred, T_pred, T_out_real
+
+
+def net_f_H(real, lam):
+    """01:621-722."""
+    A_cell, Fc, N_cells = _t(270), _t(96485), _t(5)
+    i_current = real[:, 0:1] / A_cell + 0.00001
+    h2_flow_raw = real[:, 6:7] + 1e-6
+    I_total = i_current * A_cell
+    n_H2_rate = I_total / (2 * Fc) * N_cells
+    Q = n_H2_rate * _t(22.4)
+    Q = Q * 60
+    Q = torch.clamp(Q, min=_t(1e-8))
+    l1, l2, l3 = lam["lambda_H1"], lam["lambda_H2"], lam["lambda_H3"]
+    I_norm = I_total / _t(100.0)
+    I_thr_norm = l3 / _t(100.0)
+    target = torch.where(I_total <= l3, l1 + l2 * I_norm, l1 + l2 * I_thr_norm)
+    actual = h2_flow_raw / Q
+    return actual - target, actual, target, I_total, l3
+
+
+def net_f_O(real, lam):
+    """01:535-619."""
+    A_cell, Fc, N_cells = _t(270), _t(96485), _t(5)
+    i_current = real[:, 0:1] / A_cell + 0.00001
+    air_flow = real[:, 7:8] + 1e-6
+    I_stack = i_current * A_cell
+    n_O2 = (I_stack * N_cells) / (4 * Fc)
+    Q = n_O2 * _t(22.4)
+    Q = Q * 60
+    Q = torch.clamp(Q, min=_t(1e-8))
+    l1, l2, l3 = lam["lambda_O1"], lam["lambda_O2"], lam["lambda_O3"]
+    I_thr = torch.abs(l3)
+    I_norm = I_stack / _t(100.0)
+    I_thr_norm = I_thr / _t(100.0)
+    target = torch.where(I_stack <= I_thr, l1 + l2 * I_norm, l1 + l2 * I_thr_norm)
+    target = torch.clamp(target, min=1.05, max=15.0)
+    o2_flow = air_flow * _t(0.21)
+    actual = o2_flow / Q
+    f = actual - target
+    f = f + torch.clamp(1.0 - actual, min=0.0) * 10.0
+    return f, actual, target, Q, o2_flow
+
+
+def net_f_T(real, u_norm_prev, y_min, y_scale, lam):
+    """01:767-867 (row t-1 -> t Euler energy balance; not on the training path).
+    u_norm_prev: DNN output on rows [:-1]."""
+    n = real.shape[0]
+    if n < 2:
+        z = torch.zeros(n, 1)
+        return z, z.clone(), z.clone()
+    A_cell, N_cells = _t(270), _t(5)
+    i_current = real[:, 0:1] / A_cell + 0.00001
+    m_coolant = real[:, 1:2] + 1e-6
+    T_in = real[:, 2:3]
+    T_out = real[:, 5:6]
+    cp_coolant, dt, h_air, A_surface, T_amb = _t(4180.0), _t(0.1), _t(20.0), _t(0.2), _t(25.0)
+    i_prev, m_prev, Tin_prev, Tout_prev = i_current[:-1], m_coolant[:-1], T_in[:-1], T_out[:-1]
+    I_prev = i_prev * A_cell
+    Tk_prev = Tout_prev + 273.15
+    V_rev = 1.229 - 0.0009 * (Tk_prev - 298.15)
+    V_tot = torch.from_numpy(denorm(u_norm_prev.detach().numpy(), y_min, y_scale))
+    V_single = V_tot / N_cells
+    Q_el = (I_prev * V_rev - I_prev * V_single) * lam["lambda_T4"]
+    Q_cool = m_prev * cp_coolant * (Tout_prev - Tin_prev) * lam["lambda_T1"]
+    Q_rad = h_air * A_surface * (Tout_prev - T_amb) * lam["lambda_T3"]
+    dT = (Q_el - Q_cool - Q_rad) / lam["lambda_T2"]
+    T_next = Tout_prev + dT * dt
+    T_full = torch.cat([T_out[0:1], T_next], dim=0)
+    return T_out - T_full, T_full, T_out
+
+
+STAGES = {
+    # name: (trainable lambda names in optimizer order, lr0, gamma, bounds)   SURVEY §9.1
+    "lambda": (["lambda_1", "lambda_2", "lambda_3", "lambda_4"], 1e-3, 0.8,
+               [(0.167 * 0.5, 0.167 * 5), (2.36e-6 * 0.1, 2.36e-6 * 2.1), (2.0, 2.0 * 5.2), (0.1, 10.0)]),
+    "thermal": (["lambda_T1", "lambda_T2", "lambda_T3", "lambda_T4", "lambda_T5"], 1.0, 0.8,
+                [(-10000.0, 10000.0)] * 5),
+    "hydrogen": (["lambda_H1", "lambda_H2", "lambda_H3", "lambda_H4"], 1e-1, 0.9,
+                 [(0.5, 50.0), (-20.0, 20.0), (50.0, 1000.0), (0.0, 20.0)]),
+    "oxygen": (["lambda_O1", "lambda_O2", "lambda_O3", "lambda_O4"], 1e-2, 0.9,
+               [(1.5, 8.0), (-20.0, 20.0), (50.0, 1000.0), (0.0, 20.0)]),
+}
+
+
+def stage_loss(stage, real, lam, y=None, u_eval=None, y_min=None, y_scale=None, u_scal=None, dnn_para=False):
+    """Loss of one physics-parameter stage (01:1008-1034, 1109-1112, 1357-1360, 1207-1222).
+    Returns (total_loss, physics_loss)."""
+    if stage == "lambda":
+        f, _, _, _, _, V_est5, *_ = net_f_V(real, u_eval, y_min, y_scale, lam)
+        scale_y, min_y = target_affine(u_scal)
+        V_norm = V_est5 * scale_y + min_y
+        physics = torch.mean(f ** 2) if dnn_para else torch.mean((y - V_norm) ** 2)
+        data = torch.mean((y - u_eval) ** 2)
+        return physics + data, physics
+    if stage == "thermal":
+        f = net_f_T_simple(real, lam)[0]
+    elif stage == "hydrogen":
+        f = net_f_H(real, lam)[0]
+    else:
+        f = net_f_O(real, lam)[0]
+    loss = torch.mean(f ** 2)
+    return loss, loss
+
+
+def run_stage(stage, n_iter, real, lam, **kw):
+    """n_iter iterations of a physics-parameter stage: Adam -> clamp(.data) -> StepLR
+    (01:1036-1055 and the three siblings).  Mutates and returns `lam`; also returns the
+    per-iteration trajectory [n_iter, n_params] (float64 view of the float32 values)."""
+    names, lr0, gamma, bounds = STAGES[stage]
+    ps = [lam[n].detach().clone().requires_grad_(True) for n in names]
+    for n, p in zip(names, ps):
+        lam[n] = p
+    opt = AdamState(ps)
+    traj = []
+    for epoch in range(n_iter):
+        total, _ = stage_loss(stage, real, lam, **kw)
+        grads = torch.autograd.grad(total, ps, allow_unused=True)
+        with torch.no_grad():
+            opt.step(ps, list(grads), steplr(lr0, gamma, 1000, epoch))
+            for p, (lo, hi) in zip(ps, bounds):
+                p.copy_(torch.clamp(p, lo, hi))
+        traj.append([float(p.item()) for p in ps])
+    for n, p in zip(names, ps):
+        lam[n] = p.detach()
+    return lam, np.array(traj)
+
+
+# ----------------------------------------------------------------------------------------
+# MC-dropout (01:1413-1491) on explicit masks, reduced the way numpy reduces it
+# ----------------------------------------------------------------------------------------
+def mc_dropout(params, x, p_mc, T, mask_fn):
+    """pred_mean, a_u, e_u [N] float32.  mask_fn(t) -> list of keep-masks of pass t.
+    pred_mean = eval forward (mean of T identical copies, 01:1480);
+    a_u = sqrt(exp(mean_t logvar_t)) (01:1483); e_u = sqrt(var_t u_t), ddof=0 (01:1486)."""
+    n_hidden = (len(params) - 8) // 2
+    with torch.no_grad():
+        u_eval, _ = mlp_forward(params, x)
+        us, lvs = [], []
+        for t in range(T):
+            u, lv = mlp_forward(params, x, [p_mc] * (n_hidden + 1), mask_fn(t))
+            us.append(u.numpy())
+            lvs.append(lv.numpy())
+    us, lvs = np.array(us), np.array(lvs)
+    pred_mean = u_eval.numpy().squeeze()
+    a_u = np.sqrt(np.exp(np.mean(lvs, axis=0))).squeeze()
+    e_u = np.sqrt(np.var(us, axis=0)).squeeze()
+    return pred_mean, a_u, e_u
+
+
+# ----------------------------------------------------------------------------------------
+# Results assembly (01:1830-2047)
+# ----------------------------------------------------------------------------------------
+def moving_average_centered(arr, window):
+    """pandas `rolling(window, center=True, min_periods=1).mean()` semantics (01:1832-1834):
+    for an even window the rows covered are [i - window//2, i + window//2 - 1], clipped."""
+    arr = np.asarray(arr, dtype=np.float64)
+    n = len(arr)
+    out = np.empty(n, dtype=np.float64)
+    half = window // 2
+    right = half - 1 if window % 2 == 0 else half
+    cs = np.concatenate([[0.0], np.cumsum(arr)])
+    for i in range(n):
+        s = max(0, i - half)
+        e = min(n, i + right + 1)
+        out[i] = arr[s:e].mean() if e > s else np.nan
+    return out
+
+
+def smooth_by_segments(values, boundary_lines, window):
+    """01:1848-1872."""
+    values = np.asarray(values, dtype=float).copy()
+    n = len(values)
+    out = np.empty_like(values, dtype=float)
+    if not boundary_lines or boundary_lines[-1] != n:
+        if not boundary_lines or boundary_lines[-1] < n:
+            return moving_average_centered(values, window)
+        boundary_lines = [b for b in boundary_lines if 0 < b <= n]
+    starts = [0] + list(boundary_lines[:-1])
+    for s, e in zip(starts, boundary_lines):
+        out[s:e] = moving_average_centered(values[s:e], window)
+    return out
+
+
+def fault_labels(n_samples, data_info):
+    """01:2013-2047 (labels only, no printing)."""
+    lab = np.zeros(n_samples)
+    if data_info and "boundary_lines" in data_info and "fault_data_list" in data_info:
+        for i in range(len(data_info["fault_data_list"])):
+            lab[data_info["boundary_lines"][i]:data_info["boundary_lines"][i + 1]] = i + 1
+    return lab
