@@ -1,0 +1,173 @@
+/* pinn_hip.h -- C ABI of the MI355X (gfx950) PINN training + MC-dropout hot path.
+ *
+ * The reference (ZhendongS/Physics-Informed-Neural-Network-...-Fuel-Cells) has no FFI or
+ * plugin interface: its hot path is the Python object surface of
+ * 01_train_pinn_multiphysics_model.py (cited as 01:<line>).  Each entry point below
+ * replaces the torch/sklearn/numpy work underneath one group of those methods; the
+ * Python classes in the package keep the reference's names and signatures on top
+ * (INTEGRATION.md shows the ctypes binding a maintainer of the reference would add).
+ *
+ * Conventions: every pointer named d_* is DEVICE memory owned by the caller (e.g. a torch
+ * tensor's data_ptr()); every call is asynchronous on `stream` (a hipStream_t passed as
+ * void*), allocates nothing, never synchronises the device and returns 0 on success or a
+ * negative PINN_E_* / positive hipError_t code.  Nothing throws across the ABI.
+ * One host thread per process/GPU drives the library; it is not re-entrant per workspace.
+ */
+#ifndef PINN_HIP_H
+#define PINN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PINN_ABI_VERSION 1
+
+/* error codes (negative; positive values are hipError_t) */
+#define PINN_OK 0
+#define PINN_E_ARG (-1)        /* null pointer / negative size / bad flag */
+#define PINN_E_ARCH (-2)       /* network shape not supported by the fused kernels */
+#define PINN_E_WORKSPACE (-3)  /* workspace too small */
+
+/* ---- physics parameters: float[17] on the device, order of 01:453-517 ------------------ */
+enum {
+  PINN_L1 = 0, PINN_L2, PINN_L3, PINN_L4,            /* voltage: r, io, il, (unused) */
+  PINN_LT1, PINN_LT2, PINN_LT3, PINN_LT4, PINN_LT5,  /* thermal */
+  PINN_LH1, PINN_LH2, PINN_LH3, PINN_LH4,            /* hydrogen */
+  PINN_LO1, PINN_LO2, PINN_LO3, PINN_LO4,            /* oxygen */
+  PINN_NLAMBDA = 17
+};
+
+/* ---- MinMaxScaler affine maps (host struct, passed by pointer, copied at call time) ----
+ * x_phys = (x_n - x_min[c]) / x_scale[c]  : sklearn inverse_transform (01:542, 629, 726, 879)
+ *   evaluated as two float64-operand steps each rounded to float32, like numpy does in place.
+ * y likewise for the DNN output (01:735).  vn_scale / vn_min: the float32 pair train_lambda
+ * builds at 01:1017-1022 to map the physics voltage back to normalised units. */
+typedef struct pinn_affine {
+  double x_min[8];
+  double x_scale[8];
+  double y_min;
+  double y_scale;
+  float vn_scale;
+  float vn_min;
+} pinn_affine_t;
+
+/* ---- residual pass: net_f_V / net_f_T_simple / net_f_H / net_f_O  (01:724-765, 869-914,
+ *      621-722, 535-619) + the stage losses mean(f^2) and their lambda gradients ---------- */
+#define PINN_RES_V 1u
+#define PINN_RES_T 2u
+#define PINN_RES_H 4u
+#define PINN_RES_O 8u
+#define PINN_RES_ALL 15u
+
+/* per-row output columns (column-major: d_cols[c * ld + row]) */
+enum {
+  PINN_C_FV = 0, PINN_C_VACT, PINN_C_VOHM, PINN_C_VCONC, PINN_C_ENERNST, PINN_C_VEST5, PINN_C_I, PINN_C_VOUT5,
+  PINN_C_FT, PINN_C_TPRED, PINN_C_TOUT,
+  PINN_C_FH, PINN_C_ACTH, PINN_C_TGTH, PINN_C_ITOT,
+  PINN_C_FO, PINN_C_ACTO, PINN_C_TGTO, PINN_C_QO2, PINN_C_O2FLOW,
+  PINN_NCOLS = 20
+};
+
+/* reduced sums (double[PINN_NSUMS], sums over rows -- divide by the GLOBAL row count) */
+enum {
+  PINN_S_FV2 = 0, PINN_S_FV_D1, PINN_S_FV_D2, PINN_S_FV_D3, /* sum f_V^2, sum f_V * df_V/dlambda_k        */
+  PINN_S_YV2, PINN_S_YV_D1, PINN_S_YV_D2, PINN_S_YV_D3,     /* sum (y-Vn)^2, sum (y-Vn) * df_V/dlambda_k   */
+  PINN_S_YU2,                                               /* sum (y-u)^2  (data loss, 01:1033)           */
+  PINN_S_FT2, PINN_S_FT_D1, PINN_S_FT_D3, PINN_S_FT_D5, PINN_S_FT_ABS,
+  PINN_S_FH2, PINN_S_FH_D1, PINN_S_FH_D2, PINN_S_FH_D3, PINN_S_ACTH, PINN_S_TGTH,
+  PINN_S_FO2, PINN_S_FO_D1, PINN_S_FO_D2, PINN_S_FO_D3, PINN_S_ACTO, PINN_S_TGTO,
+  PINN_NSUMS = 32
+};
+
+/* Workspace (bytes) pinn_residuals needs for its per-workgroup partial sums. */
+size_t pinn_residuals_workspace_bytes(void);
+
+/* One pass over n_rows normalised rows.
+ *   d_x      [n_rows, 8] row-major float32 (normalised inputs)
+ *   d_u      [n_rows] DNN mean output, normalised (needed iff flags & PINN_RES_V), else NULL
+ *   d_y      [n_rows] normalised target or NULL (then the YV / YU sums are 0)
+ *   d_lambda [17] float32
+ *   d_cols   NULL, or PINN_NCOLS columns of leading dimension ld >= n_rows
+ *   d_sums   NULL, or double[PINN_NSUMS]: overwritten with this call's sums (deterministic:
+ *            per-workgroup partials in d_work, then a fixed-order final reduction)
+ */
+int pinn_residuals(const float* d_x, const float* d_u, const float* d_y, const pinn_affine_t* aff,
+                   const float* d_lambda, unsigned flags, long long n_rows,
+                   float* d_cols, long long ld, double* d_sums, void* d_work, size_t work_bytes,
+                   void* stream);
+
+/* ---- physics-parameter stage step: grads from sums -> Adam -> clamp (01:1036-1047 and the
+ *      three sibling trainers).  Runs on the device so a stage needs no host round trip. ---- */
+enum { PINN_STAGE_LAMBDA_PM = 0, /* train_lambda(dnn_para=False): loss mean((y-Vn)^2)+mean((y-u)^2) */
+       PINN_STAGE_LAMBDA_F = 1,  /* train_lambda(dnn_para=True):  loss mean(f_V^2)+mean((y-u)^2)    */
+       PINN_STAGE_THERMAL = 2, PINN_STAGE_HYDROGEN = 3, PINN_STAGE_OXYGEN = 4 };
+
+/* d_adam: float[2*17] first/second moments (caller zeroes at stage start), d_loss: float[2]
+ * (total, physics) written for logging.  `step` is the 1-based Adam step of this stage,
+ * `lr` the StepLR-scheduled rate of this epoch, n_global the global row count. */
+int pinn_lambda_step(int stage, const double* d_sums, long long n_global, float vn_scale,
+                     float lr, int step, float* d_lambda, float* d_adam, float* d_loss, void* stream);
+
+/* ---- the network ------------------------------------------------------------------------
+ * Architecture [n_in=8, hidden x n_hidden, 1] + variance head hidden -> hidden/2 -> hidden/4 -> 1
+ * (01:389-438).  Parameters live in ONE flat float32 device buffer in state_dict order,
+ * each tensor in torch layout [out, in] row-major:
+ *   W_0 b_0 ... W_{h-1} b_{h-1}  W_p b_p  Wv_0 bv_0  Wv_1 bv_1  Wv_2 bv_2
+ * The fused kernels support hidden in {128, 256} (hidden % 128 == 0, <= 256), 1 <= n_hidden <= 8.
+ */
+typedef struct pinn_net {
+  int n_in;      /* 8 */
+  int hidden;    /* H */
+  int n_hidden;  /* number of H-wide hidden layers (3 in the reference, 01:2139) */
+} pinn_net_t;
+
+long long pinn_param_count(const pinn_net_t* net);          /* floats in the flat buffer, <0 on error */
+
+/* dropout source */
+enum { PINN_DROP_NONE = 0,   /* eval mode: identity                                              */
+       PINN_DROP_PHILOX = 1, /* on-chip Philox4x32-10, keyed (seed, stream, global row, layer, f) */
+       PINN_DROP_BITS = 2 }; /* injected bit-packed keep-masks (parity tests)         */
+
+typedef struct pinn_dropout {
+  int mode;
+  float p[9];                 /* drop probability of dropout module l (hidden 0..n_hidden-1, then var head) */
+  unsigned long long seed;    /* PHILOX */
+  unsigned stream;            /* PHILOX: optimizer step / first pass index */
+  long long row_offset;       /* global index of local row 0 (data-parallel shards) */
+  const unsigned* d_bits;     /* BITS: [n_passes][n_rows][words] uint32, bit f of module l at
+                                 word offset l*(H/32) (+ f/32), words = n_hidden*H/32 + H/64 */
+} pinn_dropout_t;
+
+/* DNN.forward (01:421-438): d_u, d_logvar [n_rows]. */
+int pinn_mlp_forward(const pinn_net_t* net, const float* d_params, const float* d_x, long long n_rows,
+                     const pinn_dropout_t* drop, float* d_u, float* d_logvar, void* stream);
+
+/* get_MC_samples (01:1413-1491) as one persistent launch: 1 eval pass + T stochastic passes
+ * per row tile, reduced on chip.  d_pred_mean, d_a_u, d_e_u [n_rows] (normalised units). */
+int pinn_mc_dropout(const pinn_net_t* net, const float* d_params, const float* d_x, long long n_rows,
+                    const pinn_dropout_t* drop, int n_passes,
+                    float* d_pred_mean, float* d_a_u, float* d_e_u, void* stream);
+
+/* train_dnn forward + aleatoric_loss + backward (01:949-953) on a row shard.
+ *   d_grads  [pinn_param_count] : SUM over local rows of d(loss_row)/dparam, already divided by
+ *            n_global (so an all-reduce(SUM) over shards gives the full-batch gradient)
+ *   d_loss   double[4]: sum_rows nll term, sum |logvar|, sum (y-u)^2, (spare) -- raw sums
+ *   workspace from pinn_train_workspace_bytes(net, n_rows)
+ */
+size_t pinn_train_workspace_bytes(const pinn_net_t* net, long long n_rows);
+int pinn_mlp_train_grads(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y,
+                         long long n_rows, long long n_global, const pinn_dropout_t* drop,
+                         float* d_grads, double* d_loss, void* d_work, size_t work_bytes, void* stream);
+
+/* torch.optim.Adam defaults (01:939): flat vectors of n floats; step is 1-based. */
+int pinn_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, long long n,
+                   float lr, int step, void* stream);
+
+int pinn_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINN_HIP_H */

@@ -1,0 +1,215 @@
+// pinn_mlp.hip -- DNN.forward (01:421-438) and get_MC_samples (01:1413-1491) for gfx950.
+//
+// K2 mlp_forward_kernel : eval / stochastic forward, persistent over 128-row tiles.
+// K3 mc_dropout_kernel  : 1 eval pass + T stochastic passes per tile inside one persistent
+//                         launch; running sums of u, u^2, logvar stay in registers, masks come
+//                         from on-chip Philox keyed by (seed, pass, global row, layer, feature);
+//                         HBM traffic is 32 B in + 12 B out per row regardless of T.
+// Both are MFMA-bound (v_mfma_f32_32x32x2_f32, exact fp32); see pinn_mlp_core.h for the layout.
+#include "pinn_mlp_core.h"
+
+namespace pinn {
+
+struct FwdArgs {
+  const float* params;
+  const float* x;
+  long long n_rows;
+  int H, nh;
+  DropDev drop;
+  int n_passes;          // MC only
+  float* o0;             // forward: u        | MC: pred_mean
+  float* o1;             // forward: logvar   | MC: a_u
+  float* o2;             //                   | MC: e_u
+};
+
+// one forward pass of the whole net for this wave's 32 rows -> (u, z) per lane (both halves hold it)
+template <int H>
+__device__ __forceinline__ void forward_pass(const float* __restrict__ params, const ParamLayout& L, Pipe& pipe,
+                                             const DropDev& d, int mode, const f32x4& xa, const f32x4& xb, int lane,
+                                             long long grow, long long lrow, long long n_rows, unsigned pass, float& u,
+                                             float& z) {
+  constexpr int NB = H / 32, NB2 = H / 64, NB4 = H / 128;
+  const int hh = lane >> 5;
+  f32x16 h[NB];
+  layer_input<NB>(h, params + L.w0(), params + L.b0(), xa, xb, lane);
+  epilogue_tanh_drop<NB>(h, d, mode, 0, hh, grow, lrow, n_rows, pass, nullptr);
+#pragma unroll 1
+  for (int l = 1; l < L.nh; ++l) {
+    f32x16 acc[NB];
+    load_bias<NB>(acc, params + L.b(l), hh);
+    layer_forward<NB, NB>(acc, h, pipe, lane);
+    epilogue_tanh_drop<NB>(acc, d, mode, l, hh, grow, lrow, n_rows, pass, nullptr);
+#pragma unroll
+    for (int mt = 0; mt < NB; ++mt) h[mt] = acc[mt];
+  }
+  u = head_dot<NB>(h, params + L.wp(), hh) + params[L.bp()];
+  f32x16 v1[NB2];
+  load_bias<NB2>(v1, params + L.bv0(), hh);
+  layer_forward<NB, NB2>(v1, h, pipe, lane);
+  epilogue_tanh_drop<NB2>(v1, d, mode, L.nh, hh, grow, lrow, n_rows, pass, nullptr);
+  f32x16 v2[NB4];
+  load_bias<NB4>(v2, params + L.bv1(), hh);
+  layer_forward<NB2, NB4>(v2, v1, pipe, lane);
+#pragma unroll
+  for (int mt = 0; mt < NB4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v2[mt][r] = tanh_f32(v2[mt][r]);
+  z = head_dot<NB4>(v2, params + L.wv2(), hh) + params[L.bv2()];
+}
+
+template <int H, bool MC>
+__global__ __launch_bounds__(kThreads, 1) void mlp_kernel(FwdArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds_w[2 * kChunkBytes];
+  __shared__ ChunkDesc tab[kMaxChunks];
+  ParamLayout L{a.H, a.nh};
+  const int n_chunks = (a.nh - 1) * (H / 32) + H / 32 + H / 64;
+  if (threadIdx.x == 0) build_forward_chunks(tab, L, 0);
+  __syncthreads();
+  Pipe pipe;
+  pipe.params = a.params; pipe.tab = tab; pipe.lds = lds_w; pipe.n = n_chunks;
+  pipe.prime();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long lrow = tile * kTileRows + wave * kWaveRows + (lane & 31);
+    const bool valid = lrow < a.n_rows;
+    const long long srow = valid ? lrow : a.n_rows - 1;
+    const long long grow = a.drop.row_offset + lrow;
+    const f32x4 xa = reinterpret_cast<const f32x4*>(a.x)[srow * 2];
+    const f32x4 xb = reinterpret_cast<const f32x4*>(a.x)[srow * 2 + 1];
+    if (!MC) {
+      float u, z;
+      forward_pass<H>(a.params, L, pipe, a.drop, a.drop.mode, xa, xb, lane, grow, srow, a.n_rows, 0u, u, z);
+      if (valid && lane < 32) {
+        a.o0[lrow] = u;
+        a.o1[lrow] = logf(softplus_f32(z) + 1e-6f);
+      }
+    } else {
+      // pass -1: eval (dropout off) -> pred_mean (01:1442-1445, 1480); passes 0..T-1 stochastic
+      float u_eval = 0.f, s1 = 0.f, s2 = 0.f, sl = 0.f;
+#pragma unroll 1
+      for (int t = -1; t < a.n_passes; ++t) {
+        const int mode = (t < 0) ? PINN_DROP_NONE : a.drop.mode;
+        float u, z;
+        forward_pass<H>(a.params, L, pipe, a.drop, mode, xa, xb, lane, grow, srow, a.n_rows, (unsigned)(t < 0 ? 0 : t), u, z);
+        if (t < 0) {
+          u_eval = u;
+        } else {
+          const float du = u - u_eval;           // shifted moments: var_t(u) = E[du^2] - E[du]^2
+          s1 += du;
+          s2 = fmaf(du, du, s2);
+          sl += logf(softplus_f32(z) + 1e-6f);
+        }
+      }
+      if (valid && lane < 32) {
+        const float inv_t = 1.0f / (float)a.n_passes;
+        const float m = s1 * inv_t;
+        const float var = fmaxf(s2 * inv_t - m * m, 0.0f);
+        a.o0[lrow] = u_eval;
+        a.o1[lrow] = expf(0.5f * (sl * inv_t));   // sqrt(exp(mean_t logvar_t)), 01:1483
+        a.o2[lrow] = sqrtf(var);                  // population std over passes, 01:1486
+      }
+    }
+  }
+}
+
+static int convert_drop(const pinn_net_t* net, const pinn_dropout_t* in, DropDev* out) {
+  out->mode = PINN_DROP_NONE;
+  out->bits = nullptr; out->words = 0; out->nb = net->hidden / 32;
+  out->seed_lo = out->seed_hi = 0; out->stream = 0; out->row_offset = 0;
+  for (int l = 0; l < kMaxDrop; ++l) { out->thr[l] = 0; out->scale[l] = 1.0f; }
+  if (!in) return PINN_OK;
+  if (in->mode < PINN_DROP_NONE || in->mode > PINN_DROP_BITS) return PINN_E_ARG;
+  out->mode = in->mode;
+  out->row_offset = in->row_offset;
+  if (in->mode == PINN_DROP_NONE) return PINN_OK;
+  for (int l = 0; l <= net->n_hidden; ++l) {
+    const float p = in->p[l];
+    if (!(p >= 0.0f && p < 1.0f)) return PINN_E_ARG;
+    double t = floor((double)p * 65536.0 + 0.5);
+    out->thr[l] = (unsigned)(t < 0 ? 0 : (t > 65536.0 ? 65536.0 : t));
+    out->scale[l] = 1.0f / (float)(1.0 - (double)p);
+  }
+  out->seed_lo = (unsigned)(in->seed & 0xFFFFFFFFull);
+  out->seed_hi = (unsigned)(in->seed >> 32);
+  out->stream = in->stream;
+  if (in->mode == PINN_DROP_BITS) {
+    if (!in->d_bits) return PINN_E_ARG;
+    out->bits = in->d_bits;
+    out->words = net->n_hidden * (net->hidden / 32) + net->hidden / 64;
+  }
+  return PINN_OK;
+}
+
+static int check_net(const pinn_net_t* net) {
+  if (!net) return PINN_E_ARG;
+  if (net->n_in != 8) return PINN_E_ARCH;
+  if (net->hidden != 128 && net->hidden != 256) return PINN_E_ARCH;
+  if (net->n_hidden < 1 || net->n_hidden > 8) return PINN_E_ARCH;
+  return PINN_OK;
+}
+
+static int num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+template <bool MC>
+static int launch(const pinn_net_t* net, const FwdArgs& a, void* stream) {
+  const long long n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
+  if (n_tiles == 0) return PINN_OK;
+  const int grid = (int)(n_tiles < num_cus() ? n_tiles : num_cus());
+  if (net->hidden == 256)
+    hipLaunchKernelGGL((mlp_kernel<256, MC>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((mlp_kernel<128, MC>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PINN_OK : (int)e;
+}
+
+}  // namespace pinn
+
+using namespace pinn;
+
+extern "C" long long pinn_param_count(const pinn_net_t* net) {
+  if (check_net(net) != PINN_OK) return check_net(net);
+  ParamLayout L{net->hidden, net->n_hidden};
+  return L.total();
+}
+
+extern "C" int pinn_mlp_forward(const pinn_net_t* net, const float* d_params, const float* d_x, long long n_rows,
+                                const pinn_dropout_t* drop, float* d_u, float* d_logvar, void* stream) {
+  int rc = check_net(net);
+  if (rc) return rc;
+  if (!d_params || !d_x || !d_u || !d_logvar || n_rows < 0) return PINN_E_ARG;
+  FwdArgs a{};
+  a.params = d_params; a.x = d_x; a.n_rows = n_rows; a.H = net->hidden; a.nh = net->n_hidden;
+  rc = convert_drop(net, drop, &a.drop);
+  if (rc) return rc;
+  a.n_passes = 1; a.o0 = d_u; a.o1 = d_logvar; a.o2 = nullptr;
+  return launch<false>(net, a, stream);
+}
+
+extern "C" int pinn_mc_dropout(const pinn_net_t* net, const float* d_params, const float* d_x, long long n_rows,
+                               const pinn_dropout_t* drop, int n_passes, float* d_pred_mean, float* d_a_u, float* d_e_u,
+                               void* stream) {
+  int rc = check_net(net);
+  if (rc) return rc;
+  if (!d_params || !d_x || !d_pred_mean || !d_a_u || !d_e_u || n_rows < 0 || n_passes < 1 || !drop) return PINN_E_ARG;
+  if (drop->mode == PINN_DROP_NONE) return PINN_E_ARG;
+  FwdArgs a{};
+  a.params = d_params; a.x = d_x; a.n_rows = n_rows; a.H = net->hidden; a.nh = net->n_hidden;
+  rc = convert_drop(net, drop, &a.drop);
+  if (rc) return rc;
+  a.n_passes = n_passes; a.o0 = d_pred_mean; a.o1 = d_a_u; a.o2 = d_e_u;
+  return launch<true>(net, a, stream);
+}
+
+extern "C" int pinn_abi_version(void) { return PINN_ABI_VERSION; }

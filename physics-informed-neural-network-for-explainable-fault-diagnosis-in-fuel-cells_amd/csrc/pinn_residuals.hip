@@ -1,0 +1,345 @@
+// pinn_residuals.hip -- fused physics-residual pass for gfx950 (HBM-bound, K1 of DESIGN.md).
+//
+// One pass over the normalised rows evaluates the four residual models of the reference
+//   net_f_V 01:724-765, net_f_T_simple 01:869-914, net_f_H 01:621-722, net_f_O 01:535-619
+// (01 = 01_train_pinn_multiphysics_model.py), optionally stores their per-row tuples, and
+// reduces every sum the five physics-parameter trainers need (stage loss + analytic
+// d loss / d lambda) with wave64 shuffles -> LDS -> one partial per workgroup,
+// finished by a fixed-order second kernel (bitwise reproducible, no float atomics).
+//
+// Compiled with -ffp-contract=off: every float op below is rounded exactly like the
+// reference's separate torch ops, so only the transcendental calls can differ (<= 2 ulp).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "../../include/pinn_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 2048;   // 256 CUs x 8 resident workgroups; grid-stride beyond
+
+struct AffineDev {
+  double x_min[8];
+  double x_scale[8];
+  double y_min, y_scale;
+  float vn_scale, vn_min;
+};
+
+__device__ __forceinline__ float denorm(float v, double mn, double sc) {
+  // numpy in-place `X -= min_; X /= scale_` on a float32 array with float64 operands
+  float t = (float)((double)v - mn);
+  return (float)((double)t / sc);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <bool kCols>
+__global__ __launch_bounds__(kThreads) void residuals_kernel(
+    const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ y, AffineDev aff,
+    const float* __restrict__ lambdas, unsigned flags, long long n_rows, float* __restrict__ cols, long long ld,
+    double* __restrict__ partials) {
+  __shared__ double red[kThreads / 64][PINN_NSUMS];
+  const float l1 = lambdas[PINN_L1], l2 = lambdas[PINN_L2], l3 = lambdas[PINN_L3];
+  const float lT1 = lambdas[PINN_LT1], lT3 = lambdas[PINN_LT3], lT5 = lambdas[PINN_LT5];
+  const float lH1 = lambdas[PINN_LH1], lH2 = lambdas[PINN_LH2], lH3 = lambdas[PINN_LH3];
+  const float lO1 = lambdas[PINN_LO1], lO2 = lambdas[PINN_LO2], lO3 = lambdas[PINN_LO3];
+
+  // 01:745-753  P_H2O from Tc = 55 (all float32 tensor ops in the reference)
+  const float Tc = 55.0f;
+  const float xw = ((-2.1794f + 0.02953f * Tc) - 9.1837e-5f * (Tc * Tc)) + 1.4454e-7f * ((Tc * Tc) * Tc);
+  const float P_H2O = powf(10.0f, xw);
+
+  float acc[PINN_NSUMS];
+#pragma unroll
+  for (int s = 0; s < PINN_NSUMS; ++s) acc[s] = 0.0f;
+
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long row = (long long)blockIdx.x * kThreads + threadIdx.x; row < n_rows; row += stride) {
+    const float4 xa = reinterpret_cast<const float4*>(x)[row * 2];
+    const float4 xb = reinterpret_cast<const float4*>(x)[row * 2 + 1];
+    const float r0 = denorm(xa.x, aff.x_min[0], aff.x_scale[0]);   // I [A]
+    const float r1 = denorm(xa.y, aff.x_min[1], aff.x_scale[1]);   // coolant flow
+    const float r2 = denorm(xa.z, aff.x_min[2], aff.x_scale[2]);   // T_in
+    const float r3 = denorm(xa.w, aff.x_min[3], aff.x_scale[3]);   // P_H2
+    const float r4 = denorm(xb.x, aff.x_min[4], aff.x_scale[4]);   // P_air
+    const float r5 = denorm(xb.y, aff.x_min[5], aff.x_scale[5]);   // T_out
+    const float r6 = denorm(xb.z, aff.x_min[6], aff.x_scale[6]);   // H2 flow
+    const float r7 = denorm(xb.w, aff.x_min[7], aff.x_scale[7]);   // air flow
+    const float yv = (y != nullptr) ? y[row] : 0.0f;
+
+    const float i5 = r0 / 270.0f + 1e-5f;        // 01:730, 639, 553
+    const float It = i5 * 270.0f;                // 01:654, 557
+
+    if (flags & PINN_RES_V) {
+      const float un = u[row];
+      const float Tk = r5 + 273.15f;
+      const float P_H2 = r3 / 101.0f + 1.0f;
+      const float P_air = r4 / 101.0f + 1.0f;
+      const float Tk_p = powf(Tk, 1.334f);
+      const float pp_H2 = 0.5f * (P_H2 / expf(1.653f * i5 / Tk_p) - P_H2O);
+      const float pp_O2 = P_air / expf(4.192f * i5 / Tk_p) - P_H2O;
+      const float RT = 8.314f * Tk;
+      const float b = RT / 96485.0f;                         // R*Tk / (2*Alpha*F), 2*Alpha = 1
+      const float V_act = (-b) * logf(i5 / l2);
+      const float V_ohm = -(i5 * l1);
+      const float V_conc = (0.5f * b) * logf(1.0f - i5 / l3);
+      const float E = 220170.0f / 192970.0f - (RT * logf(P_H2O / (pp_H2 * sqrtf(pp_O2)))) / 192970.0f;
+      const float V_est = ((E + V_act) + V_ohm) + V_conc;
+      const float V_out = denorm(un, aff.y_min, aff.y_scale) / 5.0f;   // u detached, 01:734-737
+      const float f = V_est - V_out;
+      const float V_est5 = V_est * 5.0f;
+      // analytic df_V/dlambda
+      const float d1 = -i5;
+      const float d2 = b / l2;
+      const float d3 = 0.5f * b * i5 / (l3 * (l3 - i5));
+      acc[PINN_S_FV2] += f * f;
+      acc[PINN_S_FV_D1] += f * d1;
+      acc[PINN_S_FV_D2] += f * d2;
+      acc[PINN_S_FV_D3] += f * d3;
+      if (y != nullptr) {
+        const float Vn = V_est5 * aff.vn_scale + aff.vn_min;   // 01:1025
+        const float dy = yv - Vn;
+        acc[PINN_S_YV2] += dy * dy;
+        acc[PINN_S_YV_D1] += dy * d1;
+        acc[PINN_S_YV_D2] += dy * d2;
+        acc[PINN_S_YV_D3] += dy * d3;
+        const float du = yv - un;
+        acc[PINN_S_YU2] += du * du;
+      }
+      if (kCols) {
+        cols[PINN_C_FV * ld + row] = f;
+        cols[PINN_C_VACT * ld + row] = V_act;
+        cols[PINN_C_VOHM * ld + row] = V_ohm;
+        cols[PINN_C_VCONC * ld + row] = V_conc;
+        cols[PINN_C_ENERNST * ld + row] = E;
+        cols[PINN_C_VEST5 * ld + row] = V_est5;
+        cols[PINN_C_I * ld + row] = i5;
+        cols[PINN_C_VOUT5 * ld + row] = V_out * 5.0f;
+      }
+    }
+
+    if (flags & PINN_RES_T) {
+      const float i6 = r0 / 270.0f + 1e-6f;     // 01:884
+      const float mc = r1 + 1e-6f;
+      const float It6 = i6 * 270.0f;
+      const float T_pred = ((lT1 * It6 + lT3 * mc) + 0.5f * r2) + lT5;   // 01:905
+      const float f = r5 - T_pred;
+      acc[PINN_S_FT2] += f * f;
+      acc[PINN_S_FT_D1] += f * (-It6);
+      acc[PINN_S_FT_D3] += f * (-mc);
+      acc[PINN_S_FT_D5] += -f;
+      acc[PINN_S_FT_ABS] += fabsf(f);
+      if (kCols) {
+        cols[PINN_C_FT * ld + row] = f;
+        cols[PINN_C_TPRED * ld + row] = T_pred;
+        cols[PINN_C_TOUT * ld + row] = r5;
+      }
+    }
+
+    if (flags & PINN_RES_H) {
+      float Q = ((It / 192970.0f) * 5.0f) * 22.4f;   // 01:660-667
+      Q = Q * 60.0f;
+      Q = fmaxf(Q, 1e-8f);
+      const bool lin = It <= lH3;                    // 01:697-701
+      const float tgt = lin ? (lH1 + lH2 * (It / 100.0f)) : (lH1 + lH2 * (lH3 / 100.0f));
+      const float act = (r6 + 1e-6f) / Q;
+      const float f = act - tgt;
+      acc[PINN_S_FH2] += f * f;
+      acc[PINN_S_FH_D1] += -f;
+      acc[PINN_S_FH_D2] += f * (-(lin ? It / 100.0f : lH3 / 100.0f));
+      acc[PINN_S_FH_D3] += f * (-(lin ? 0.0f : lH2 / 100.0f));
+      acc[PINN_S_ACTH] += act;
+      acc[PINN_S_TGTH] += tgt;
+      if (kCols) {
+        cols[PINN_C_FH * ld + row] = f;
+        cols[PINN_C_ACTH * ld + row] = act;
+        cols[PINN_C_TGTH * ld + row] = tgt;
+        cols[PINN_C_ITOT * ld + row] = It;
+      }
+    }
+
+    if (flags & PINN_RES_O) {
+      float Q = ((It * 5.0f) / 385940.0f) * 22.4f;   // 01:564-566
+      Q = Q * 60.0f;
+      Q = fmaxf(Q, 1e-8f);
+      const float thr = fabsf(lO3);
+      const bool lin = It <= thr;                    // 01:586-590
+      const float raw = lin ? (lO1 + lO2 * (It / 100.0f)) : (lO1 + lO2 * (thr / 100.0f));
+      const float tgt = fminf(fmaxf(raw, 1.05f), 15.0f);
+      const float c = (raw >= 1.05f && raw <= 15.0f) ? 1.0f : 0.0f;   // torch.clamp backward is inclusive
+      const float o2 = (r7 + 1e-6f) * 0.21f;
+      const float act = o2 / Q;
+      const float f = (act - tgt) + fmaxf(1.0f - act, 0.0f) * 10.0f;   // 01:606-610
+      const float sgn = (lO3 > 0.0f) ? 1.0f : ((lO3 < 0.0f) ? -1.0f : 0.0f);
+      acc[PINN_S_FO2] += f * f;
+      acc[PINN_S_FO_D1] += f * (-c);
+      acc[PINN_S_FO_D2] += f * (-c * (lin ? It / 100.0f : thr / 100.0f));
+      acc[PINN_S_FO_D3] += f * (-c * (lin ? 0.0f : lO2 * sgn / 100.0f));
+      acc[PINN_S_ACTO] += act;
+      acc[PINN_S_TGTO] += tgt;
+      if (kCols) {
+        cols[PINN_C_FO * ld + row] = f;
+        cols[PINN_C_ACTO * ld + row] = act;
+        cols[PINN_C_TGTO * ld + row] = tgt;
+        cols[PINN_C_QO2 * ld + row] = Q;
+        cols[PINN_C_O2FLOW * ld + row] = o2;
+      }
+    }
+  }
+
+  if (partials == nullptr) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int s = 0; s < PINN_NSUMS; ++s) {
+    const double w = wave_sum((double)acc[s]);
+    if (lane == 0) red[wave][s] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < PINN_NSUMS) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) t += red[w][threadIdx.x];
+    partials[(long long)blockIdx.x * PINN_NSUMS + threadIdx.x] = t;
+  }
+}
+
+// fixed-order final reduction: thread (s, j) sums partials j, j+8, ... then 8 -> 1 in LDS order
+__global__ __launch_bounds__(256) void residuals_finalize(const double* __restrict__ partials, int n_blocks,
+                                                          double* __restrict__ sums) {
+  __shared__ double red[8][PINN_NSUMS];
+  const int s = threadIdx.x & 31, j = threadIdx.x >> 5;
+  double t = 0.0;
+  for (int b = j; b < n_blocks; b += 8) t += partials[(long long)b * PINN_NSUMS + s];
+  red[j][s] = t;
+  __syncthreads();
+  if (threadIdx.x < PINN_NSUMS) {
+    double r = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r += red[k][threadIdx.x];
+    sums[threadIdx.x] = r;
+  }
+}
+
+// Adam (torch defaults) + clamp for the <= 5 scalars of a physics stage, one thread.
+struct StageDef {
+  int n;
+  int idx[5];
+  float lo[5], hi[5];
+};
+
+__global__ void lambda_step_kernel(int stage, const double* __restrict__ sums, double inv_n, float vn_scale, float lr,
+                                   int step, float* __restrict__ lambdas, float* __restrict__ adam,
+                                   float* __restrict__ loss_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  StageDef d;
+  float g[5];
+  bool has_grad[5];
+  float total = 0.f, physics = 0.f;
+  if (stage == PINN_STAGE_LAMBDA_PM || stage == PINN_STAGE_LAMBDA_F) {
+    // 01:992-997 bounds; lambda_4 is in the optimizer but never receives a gradient
+    d.n = 4;
+    d.idx[0] = PINN_L1; d.idx[1] = PINN_L2; d.idx[2] = PINN_L3; d.idx[3] = PINN_L4;
+    d.lo[0] = (float)(0.167 * 0.5); d.hi[0] = (float)(0.167 * 5);
+    d.lo[1] = (float)(2.36e-6 * 0.1); d.hi[1] = (float)(2.36e-6 * 2.1);
+    d.lo[2] = 2.0f; d.hi[2] = (float)(2.0 * 5.2);
+    d.lo[3] = 0.1f; d.hi[3] = 10.0f;
+    has_grad[3] = false; g[3] = 0.f;
+    if (stage == PINN_STAGE_LAMBDA_F) {
+      physics = (float)(sums[PINN_S_FV2] * inv_n);
+      for (int k = 0; k < 3; ++k) { g[k] = (float)(2.0 * sums[PINN_S_FV_D1 + k] * inv_n); has_grad[k] = true; }
+    } else {
+      physics = (float)(sums[PINN_S_YV2] * inv_n);
+      // d/dlambda mean((y - (5 V_est s + m))^2) = -(2/N) * 5 s * sum (y - Vn) df/dlambda
+      for (int k = 0; k < 3; ++k) {
+        g[k] = (float)(-2.0 * 5.0 * (double)vn_scale * sums[PINN_S_YV_D1 + k] * inv_n);
+        has_grad[k] = true;
+      }
+    }
+    total = physics + (float)(sums[PINN_S_YU2] * inv_n);
+  } else if (stage == PINN_STAGE_THERMAL) {
+    d.n = 5;
+    for (int k = 0; k < 5; ++k) { d.idx[k] = PINN_LT1 + k; d.lo[k] = -10000.f; d.hi[k] = 10000.f; has_grad[k] = false; g[k] = 0.f; }
+    g[0] = (float)(2.0 * sums[PINN_S_FT_D1] * inv_n); has_grad[0] = true;
+    g[2] = (float)(2.0 * sums[PINN_S_FT_D3] * inv_n); has_grad[2] = true;
+    g[4] = (float)(2.0 * sums[PINN_S_FT_D5] * inv_n); has_grad[4] = true;
+    total = physics = (float)(sums[PINN_S_FT2] * inv_n);
+  } else if (stage == PINN_STAGE_HYDROGEN) {
+    d.n = 4;
+    for (int k = 0; k < 4; ++k) d.idx[k] = PINN_LH1 + k;
+    d.lo[0] = 0.5f; d.hi[0] = 50.f; d.lo[1] = -20.f; d.hi[1] = 20.f; d.lo[2] = 50.f; d.hi[2] = 1000.f; d.lo[3] = 0.f; d.hi[3] = 20.f;
+    for (int k = 0; k < 3; ++k) { g[k] = (float)(2.0 * sums[PINN_S_FH_D1 + k] * inv_n); has_grad[k] = true; }
+    has_grad[3] = false; g[3] = 0.f;
+    total = physics = (float)(sums[PINN_S_FH2] * inv_n);
+  } else {
+    d.n = 4;
+    for (int k = 0; k < 4; ++k) d.idx[k] = PINN_LO1 + k;
+    d.lo[0] = 1.5f; d.hi[0] = 8.f; d.lo[1] = -20.f; d.hi[1] = 20.f; d.lo[2] = 50.f; d.hi[2] = 1000.f; d.lo[3] = 0.f; d.hi[3] = 20.f;
+    for (int k = 0; k < 3; ++k) { g[k] = (float)(2.0 * sums[PINN_S_FO_D1 + k] * inv_n); has_grad[k] = true; }
+    has_grad[3] = false; g[3] = 0.f;
+    total = physics = (float)(sums[PINN_S_FO2] * inv_n);
+  }
+  // torch.optim.Adam (single tensor path): bias corrections in double, tensor math in float32
+  const double bc1 = 1.0 - pow(0.9, (double)step);
+  const double bc2 = 1.0 - pow(0.999, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  for (int k = 0; k < d.n; ++k) {
+    const int id = d.idx[k];
+    float p = lambdas[id];
+    if (has_grad[k]) {          // a parameter whose .grad is None is skipped entirely
+      float m = adam[id], v = adam[PINN_NLAMBDA + id];
+      m = m * 0.9f + g[k] * 0.1f;                          // lerp(m, g, 1-b1)
+      v = v * 0.999f + (g[k] * g[k]) * 0.001f;
+      const float denom = sqrtf(v) / bc2_sqrt + 1e-8f;
+      p = p - step_size * (m / denom);
+      adam[id] = m; adam[PINN_NLAMBDA + id] = v;
+    }
+    lambdas[id] = fminf(fmaxf(p, d.lo[k]), d.hi[k]);       // .data = clamp(.data, lo, hi) AFTER step
+  }
+  if (loss_out) { loss_out[0] = total; loss_out[1] = physics; }
+}
+
+}  // namespace
+
+extern "C" size_t pinn_residuals_workspace_bytes(void) { return (size_t)kMaxBlocks * PINN_NSUMS * sizeof(double); }
+
+extern "C" int pinn_residuals(const float* d_x, const float* d_u, const float* d_y, const pinn_affine_t* aff,
+                              const float* d_lambda, unsigned flags, long long n_rows, float* d_cols, long long ld,
+                              double* d_sums, void* d_work, size_t work_bytes, void* stream) {
+  if (!d_x || !aff || !d_lambda || n_rows < 0 || (flags & ~PINN_RES_ALL)) return PINN_E_ARG;
+  if ((flags & PINN_RES_V) && !d_u) return PINN_E_ARG;
+  if (d_cols && ld < n_rows) return PINN_E_ARG;
+  if (d_sums && (!d_work || work_bytes < pinn_residuals_workspace_bytes())) return PINN_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  AffineDev a;
+  for (int c = 0; c < 8; ++c) { a.x_min[c] = aff->x_min[c]; a.x_scale[c] = aff->x_scale[c]; }
+  a.y_min = aff->y_min; a.y_scale = aff->y_scale; a.vn_scale = aff->vn_scale; a.vn_min = aff->vn_min;
+  long long want = (n_rows + kThreads - 1) / kThreads;
+  int blocks = (int)(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
+  double* partials = d_sums ? (double*)d_work : nullptr;
+  if (n_rows > 0 || d_sums) {
+    if (d_cols)
+      hipLaunchKernelGGL(residuals_kernel<true>, dim3(blocks), dim3(kThreads), 0, st, d_x, d_u, d_y, a, d_lambda, flags,
+                         n_rows, d_cols, ld, partials);
+    else
+      hipLaunchKernelGGL(residuals_kernel<false>, dim3(blocks), dim3(kThreads), 0, st, d_x, d_u, d_y, a, d_lambda, flags,
+                         n_rows, d_cols, ld, partials);
+  }
+  if (d_sums) hipLaunchKernelGGL(residuals_finalize, dim3(1), dim3(256), 0, st, partials, blocks, d_sums);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PINN_OK : (int)e;
+}
+
+extern "C" int pinn_lambda_step(int stage, const double* d_sums, long long n_global, float vn_scale, float lr, int step,
+                                float* d_lambda, float* d_adam, float* d_loss, void* stream) {
+  if (stage < 0 || stage > PINN_STAGE_OXYGEN || !d_sums || n_global <= 0 || step < 1 || !d_lambda || !d_adam)
+    return PINN_E_ARG;
+  hipLaunchKernelGGL(lambda_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stage, d_sums, 1.0 / (double)n_global,
+                     vn_scale, lr, step, d_lambda, d_adam, d_loss);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PINN_OK : (int)e;
+}
