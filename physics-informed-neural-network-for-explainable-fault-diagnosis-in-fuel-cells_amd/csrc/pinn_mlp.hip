@@ -188,7 +188,9 @@ extern "C" int pinn_mlp_forward(const pinn_net_t* net, const float* d_params, co
                                 const pinn_dropout_t* drop, float* d_u, float* d_logvar, void* stream) {
   int rc = check_net(net);
   if (rc) return rc;
-  if (!d_params || !d_x || !d_u || !d_logvar || n_rows < 0) return PINN_E_ARG;
+  if (n_rows < 0 || !d_params) return PINN_E_ARG;
+  if (n_rows == 0) return PINN_OK;
+  if (!d_x || !d_u || !d_logvar) return PINN_E_ARG;
   FwdArgs a{};
   a.params = d_params; a.x = d_x; a.n_rows = n_rows; a.H = net->hidden; a.nh = net->n_hidden;
   rc = convert_drop(net, drop, &a.drop);
@@ -202,7 +204,9 @@ extern "C" int pinn_mc_dropout(const pinn_net_t* net, const float* d_params, con
                                void* stream) {
   int rc = check_net(net);
   if (rc) return rc;
-  if (!d_params || !d_x || !d_pred_mean || !d_a_u || !d_e_u || n_rows < 0 || n_passes < 1 || !drop) return PINN_E_ARG;
+  if (n_rows < 0 || !d_params || n_passes < 1 || !drop) return PINN_E_ARG;
+  if (n_rows == 0) return PINN_OK;
+  if (!d_x || !d_pred_mean || !d_a_u || !d_e_u) return PINN_E_ARG;
   if (drop->mode == PINN_DROP_NONE) return PINN_E_ARG;
   FwdArgs a{};
   a.params = d_params; a.x = d_x; a.n_rows = n_rows; a.H = net->hidden; a.nh = net->n_hidden;

@@ -310,8 +310,8 @@ extern "C" size_t pinn_residuals_workspace_bytes(void) { return (size_t)kMaxBloc
 extern "C" int pinn_residuals(const float* d_x, const float* d_u, const float* d_y, const pinn_affine_t* aff,
                               const float* d_lambda, unsigned flags, long long n_rows, float* d_cols, long long ld,
                               double* d_sums, void* d_work, size_t work_bytes, void* stream) {
-  if (!d_x || !aff || !d_lambda || n_rows < 0 || (flags & ~PINN_RES_ALL)) return PINN_E_ARG;
-  if ((flags & PINN_RES_V) && !d_u) return PINN_E_ARG;
+  if ((!d_x && n_rows > 0) || !aff || !d_lambda || n_rows < 0 || (flags & ~PINN_RES_ALL)) return PINN_E_ARG;
+  if ((flags & PINN_RES_V) && !d_u && n_rows > 0) return PINN_E_ARG;
   if (d_cols && ld < n_rows) return PINN_E_ARG;
   if (d_sums && (!d_work || work_bytes < pinn_residuals_workspace_bytes())) return PINN_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;

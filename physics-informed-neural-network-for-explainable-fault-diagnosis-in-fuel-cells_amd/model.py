@@ -1,0 +1,489 @@
+"""`DNN` and `PhysicsInformedNN` -- the reference's model surface on the gfx950 HIP library.
+
+Mirrors 01_train_pinn_multiphysics_model.py (cited 01:<line>): same constructor, attributes
+(`.dnn`, `.lambda_*`, `.x`, `.u`, `.X`, `.x_scal`, `.u_scal`), methods (`net_u`, `net_f_V`,
+`net_f_T_simple`, `net_f_T`, `net_f_H`, `net_f_O`, `aleatoric_loss`, `train_dnn`, `train_lambda`,
+`train_thermal`, `train_hydrogen`, `train_oxygen`, `predict`) and tuple orders, so the
+reference's `__main__` (01:2139-2158) and its scripts 02-05 run unchanged on top.
+
+What is underneath is different: every numeric step is a call through the C ABI of
+include/pinn_hip.h (ctypes, raw device pointers, the current HIP stream).  torch supplies
+device memory, streams and `torch.distributed`; there is no CPU fallback.
+
+Extensions (keyword-only, all optional): `seed` (Philox dropout seed), `row_offset` /
+`n_global` (this process holds rows [row_offset, row_offset+N) of an n_global-row series:
+data-parallel training with one all-reduce(SUM) of the flat gradient per step), and
+`train_dnn(..., batch_size=)` for minibatches.
+"""
+import ctypes
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib, layout
+from . import dp as _dp
+
+LAMBDA_NAMES = ["lambda_1", "lambda_2", "lambda_3", "lambda_4",
+                "lambda_T1", "lambda_T2", "lambda_T3", "lambda_T4", "lambda_T5",
+                "lambda_H1", "lambda_H2", "lambda_H3", "lambda_H4",
+                "lambda_O1", "lambda_O2", "lambda_O3", "lambda_O4"]
+# initial values: 01:453-456, 477-481, 497-500, 514-517
+LAMBDA_INIT = [0.167897923477715, 2.36682075851268e-06, 2.43414469188443, 1.0,
+               10.0, 10.0, 10.0, 10.0, 10.0,
+               5.0, -1.559, 197.715, 1.20,
+               2.0, 0.5, 200.0, 1.0]
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise _lib.PinnError("pinn_amd needs a ROCm GPU (gfx950): torch.cuda.is_available() is False and there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class DNN(torch.nn.Module):
+    """01:389-438.  Same module tree / state_dict keys as the reference; the 14 weight and
+    bias tensors are views into ONE flat float32 device buffer that the kernels read."""
+
+    def __init__(self, p, logvar, layers, seed=0):
+        super().__init__()
+        self.depth = len(layers) - 1
+        self.p = p
+        self.logvar = logvar
+        self.activation = torch.nn.Tanh
+        self.n_in, self.hidden, self.n_hidden = layout.check_arch(layers)
+        dev = _device()
+        self._lib = _lib.load()
+        self._net = _lib.Net(self.n_in, self.hidden, self.n_hidden)
+        offs, total = layout.param_offsets(self.n_in, self.hidden, self.n_hidden)
+        assert self._lib.pinn_param_count(ctypes.byref(self._net)) == total
+        self._offsets = offs
+        self._flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._flat_grad_full = torch.zeros(total + _dp.LOSS_TAIL, dtype=torch.float32, device=dev)
+        self._flat_grad = self._flat_grad_full[:total]
+
+        layer_list = []
+        for i in range(self.depth - 1):
+            layer_list.append(("layer_%d" % i, torch.nn.Linear(layers[i], layers[i + 1])))
+            layer_list.append(("activation_%d" % i, self.activation()))
+            layer_list.append(("dropout_%d" % i, torch.nn.Dropout(p=self.p)))
+        self.layers = torch.nn.Sequential(OrderedDict(layer_list))
+        self.predict = torch.nn.Linear(layers[-2], layers[-1])
+        self.var_layers = torch.nn.Sequential(
+            torch.nn.Linear(layers[-2], layers[-2] // 2), torch.nn.Tanh(), torch.nn.Dropout(p=self.p),
+            torch.nn.Linear(layers[-2] // 2, layers[-2] // 4), torch.nn.Tanh(),
+            torch.nn.Linear(layers[-2] // 4, layers[-1]))
+        # move the torch-default initial values into the flat buffer and alias the Parameters onto it
+        mods = dict(self.named_modules())
+        self._views = []
+        for name, shape, off in offs:
+            mname, pname = name.rsplit(".", 1)
+            mod = mods[mname]
+            init = getattr(mod, pname).detach()
+            n = init.numel()
+            view = self._flat[off:off + n].view(shape)
+            view.copy_(init)
+            par = torch.nn.Parameter(view)
+            par.grad = self._flat_grad[off:off + n].view(shape)
+            setattr(mod, pname, par)
+            self._views.append((mod, pname, off, n, shape))
+        self.seed = int(seed)
+        self._fwd_counter = 0
+        # parity-test hook: int32 device tensor [n_passes, N, words] of bit-packed keep-masks;
+        # when set, stochastic passes replay these masks instead of drawing Philox ones
+        self._mask_bits = None
+        self._mask_pass = 0
+
+    # -- flat buffer <-> Parameter aliasing ------------------------------------------------
+    def flat_params(self):
+        """The flat parameter buffer; re-gathers a Parameter that user code re-pointed elsewhere."""
+        base = self._flat.data_ptr()
+        for mod, pname, off, n, shape in self._views:
+            par = getattr(mod, pname)
+            if par.data_ptr() != base + 4 * off or not par.is_contiguous():
+                view = self._flat[off:off + n].view(shape)
+                view.copy_(par.detach().to(self._flat.device, torch.float32))
+                par.data = view
+        return self._flat
+
+    def dropout_modules(self):
+        return [m for _, m in self.named_modules() if isinstance(m, torch.nn.Dropout)]
+
+    def dropout_struct(self, stream_id, row_offset=0, mode=None, p_override=None):
+        d = _lib.Dropout()
+        mods = self.dropout_modules()
+        d.mode = _lib.DROP_PHILOX if mode is None else mode
+        for l, m in enumerate(mods):
+            d.p[l] = float(m.p if p_override is None else p_override)
+        d.seed = self.seed
+        d.stream = int(stream_id) & 0xFFFFFFFF
+        d.row_offset = int(row_offset)
+        d.d_bits = None
+        if self._mask_bits is not None and mode is None:
+            d.mode = _lib.DROP_BITS
+            d.d_bits = self._mask_bits[self._mask_pass].data_ptr()
+        return d
+
+    def inject_masks(self, bits):
+        """Replay recorded keep-masks (tests only). bits: int32 [n_passes, N, words] or None."""
+        self._mask_bits = None if bits is None else bits.to(self._flat.device).contiguous()
+        self._mask_pass = 0
+
+    def forward(self, x, row_offset=0):
+        """(out [N,1], logvar [N,1]) -- eval: dropout off; train: on-chip Philox masks (01:421-438)."""
+        x = x.detach().to(self._flat.device, torch.float32).contiguous()
+        n = x.shape[0]
+        u = torch.empty(n, 1, device=x.device, dtype=torch.float32)
+        lv = torch.empty(n, 1, device=x.device, dtype=torch.float32)
+        drop = None
+        if self.training and any(m.p > 0 for m in self.dropout_modules()):
+            self._fwd_counter += 1
+            drop = self.dropout_struct(0x80000000 + self._fwd_counter, row_offset)
+            if self._mask_bits is not None:
+                self._mask_pass += 1
+        rc = self._lib.pinn_mlp_forward(ctypes.byref(self._net), _ptr(self.flat_params()), _ptr(x), n,
+                                        ctypes.byref(drop) if drop is not None else None, _ptr(u), _ptr(lv), _stream())
+        _lib.check(rc, "pinn_mlp_forward")
+        if not self.logvar:
+            lv = torch.zeros_like(u)
+        return u, lv
+
+
+class PhysicsInformedNN():
+    """01:441-1410."""
+
+    def __init__(self, X, u, layers, x_scal, u_scal, p, logvar, *, seed=0, row_offset=0, n_global=None, process_group=None):
+        dev = _device()
+        self._lib = _lib.load()
+        self.x = X[:, 0:].clone().detach().float().to(dev).contiguous().requires_grad_(True)
+        self.u = u.clone().detach().float().to(dev).contiguous()
+        self.u_scal = u_scal
+        self.x_scal = x_scal
+        self.X = X
+        self.row_offset = int(row_offset)
+        self.n_local = int(self.x.shape[0])
+        self.n_global = int(n_global) if n_global is not None else self.n_local
+        self._group = process_group
+        # 17 physics parameters: one device vector, each nn.Parameter a 1-element view of it
+        self._lambda = torch.tensor(LAMBDA_INIT, dtype=torch.float32, device=dev)
+        for i, name in enumerate(LAMBDA_NAMES):
+            setattr(self, name, torch.nn.Parameter(self._lambda[i:i + 1]))
+        self.dnn = DNN(p, logvar, layers, seed=seed)
+        # registration order and the `lambda_3` <- lambda_4 overwrite of 01:465-468 are kept for state_dict parity
+        self.dnn.register_parameter("lambda_1", self.lambda_1)
+        self.dnn.register_parameter("lambda_2", self.lambda_2)
+        self.dnn.register_parameter("lambda_3", self.lambda_3)
+        self.dnn.register_parameter("lambda_3", self.lambda_4)
+        for name in LAMBDA_NAMES[4:]:
+            self.dnn.register_parameter(name, getattr(self, name))
+        self._step_counter = 0
+        self._work = {}
+        self._aff_cache = {}
+        n = self.dnn._flat.numel()
+        self._adam_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._adam_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._sums = torch.zeros(_lib.NSUMS, dtype=torch.float64, device=dev)
+        self._res_work = torch.empty(self._lib.pinn_residuals_workspace_bytes(), dtype=torch.uint8, device=dev)
+        self.verbose = True
+
+    # ------------------------------------------------------------------ helpers
+    def _lambdas(self):
+        base = self._lambda.data_ptr()
+        for i, name in enumerate(LAMBDA_NAMES):
+            par = getattr(self, name)
+            if par.data_ptr() != base + 4 * i:
+                self._lambda[i:i + 1].copy_(par.detach().reshape(1).to(self._lambda.device, torch.float32))
+                par.data = self._lambda[i:i + 1]
+        return self._lambda
+
+    def _affine(self, x_scal):
+        key = id(x_scal)
+        if key not in self._aff_cache:
+            a = _lib.Affine()
+            mn = np.asarray(x_scal.min_, dtype=np.float64).reshape(-1)
+            sc = np.asarray(x_scal.scale_, dtype=np.float64).reshape(-1)
+            if mn.size != 8:
+                raise ValueError("x scaler must have 8 features")
+            for c in range(8):
+                a.x_min[c], a.x_scale[c] = mn[c], sc[c]
+            a.y_min = float(np.asarray(self.u_scal.min_, dtype=np.float64).reshape(-1)[0])
+            a.y_scale = float(np.asarray(self.u_scal.scale_, dtype=np.float64).reshape(-1)[0])
+            # 01:1017-1022: float32 tensors
+            lo, hi = float(self.u_scal.feature_range[0]), float(self.u_scal.feature_range[1])
+            dmin = torch.tensor(np.asarray(self.u_scal.data_min_), dtype=torch.float32)
+            dmax = torch.tensor(np.asarray(self.u_scal.data_max_), dtype=torch.float32)
+            scale_y = (hi - lo) / (dmax - dmin + 1e-12)
+            min_y = lo - dmin * scale_y
+            a.vn_scale, a.vn_min = float(scale_y), float(min_y)
+            self._aff_cache[key] = (a, x_scal)      # keep the scaler alive so id() stays unique
+        return self._aff_cache[key][0]
+
+    def _dev_rows(self, X):
+        if X is self.X or X is self.x:
+            return self.x.detach()
+        return X.detach().to(self.x.device, torch.float32).contiguous()
+
+    def _residuals(self, X, x_scal, flags, u=None, y=None, cols=True, sums=False):
+        xd = self._dev_rows(X)
+        n = xd.shape[0]
+        c = torch.empty(_lib.NCOLS, n, device=xd.device, dtype=torch.float32) if cols else None
+        rc = self._lib.pinn_residuals(_ptr(xd), _ptr(u), _ptr(y), ctypes.byref(self._affine(x_scal)), _ptr(self._lambdas()),
+                                      flags, n, _ptr(c), n, _ptr(self._sums) if sums else None,
+                                      _ptr(self._res_work), self._res_work.numel(), _stream())
+        _lib.check(rc, "pinn_residuals")
+        return c
+
+    @staticmethod
+    def _col(c, name):
+        return c[_lib.C[name]].unsqueeze(1)
+
+    # ------------------------------------------------------------------ model functions
+    def net_u(self, x):
+        prediction, log_var = self.dnn(x, self.row_offset if x.shape[0] == self.n_local else 0)
+        return prediction, log_var
+
+    def net_f_V(self, X, x_scal):
+        """01:724-765 -> (f, V_act, V_ohmic, V_conc, E_nerst, V_out_est*5, i, il, V_out*5)."""
+        xd = self._dev_rows(X)
+        u, _ = self.net_u(xd)                       # in the caller's train/eval mode, detached (01:733-734)
+        c = self._residuals(xd, x_scal, _lib.RES_V, u=u.reshape(-1))
+        g = lambda n: self._col(c, n)
+        return g("FV"), g("VACT"), g("VOHM"), g("VCONC"), g("ENERNST"), g("VEST5"), g("I"), self.lambda_3, g("VOUT5")
+
+    def net_f_T_simple(self, X, x_scal):
+        """01:869-914 -> (f_T, T_out_predicted, T_out_real).  (The reference's unused DNN forward is not run.)"""
+        c = self._residuals(X, x_scal, _lib.RES_T)
+        return self._col(c, "FT"), self._col(c, "TPRED"), self._col(c, "TOUT")
+
+    def net_f_H(self, X, x_scal):
+        """01:621-722 -> (f_H2, actual_excess_ratio, target_excess_ratio, I_total, I_threshold)."""
+        c = self._residuals(X, x_scal, _lib.RES_H)
+        return self._col(c, "FH"), self._col(c, "ACTH"), self._col(c, "TGTH"), self._col(c, "ITOT"), self.lambda_H3
+
+    def net_f_O(self, X, x_scal):
+        """01:535-619 -> (f_O2, actual_excess_ratio, target_excess_ratio, Q_O2_theoretical_slpm, o2_flow_actual)."""
+        c = self._residuals(X, x_scal, _lib.RES_O)
+        return self._col(c, "FO"), self._col(c, "ACTO"), self._col(c, "TGTO"), self._col(c, "QO2"), self._col(c, "O2FLOW")
+
+    def net_f_T(self, X, x_scal):
+        """01:767-867: Euler energy balance row t-1 -> t.  Not on the training / results path
+        (SURVEY.md 8(f) F4); evaluated with elementwise device ops on the kernels' outputs."""
+        xd = self._dev_rows(X)
+        n = xd.shape[0]
+        dev = xd.device
+        if n < 2:
+            z = torch.zeros(n, 1, device=dev)
+            return z, z.clone(), z.clone()
+        c = self._residuals(xd, x_scal, _lib.RES_T | _lib.RES_H)
+        u, _ = self.net_u(xd[:-1])
+        a = self._affine(x_scal)
+        V_tot = ((u.double() - a.y_min).float().double() / a.y_scale).float()
+        It = self._col(c, "ITOT")                    # (I/270 + 1e-5) * 270
+        T_out = self._col(c, "TOUT")
+        real12 = ((xd[:, 1:3].double() - torch.tensor(list(a.x_min)[1:3], device=dev)).float().double()
+                  / torch.tensor(list(a.x_scale)[1:3], device=dev)).float()
+        m_cool, T_in = real12[:, 0:1] + 1e-6, real12[:, 1:2]
+        I_prev, m_prev, Tin_prev, Tout_prev = It[:-1], m_cool[:-1], T_in[:-1], T_out[:-1]
+        V_rev = 1.229 - 0.0009 * ((Tout_prev + 273.15) - 298.15)
+        V_single = V_tot / 5.0
+        Q_el = (I_prev * V_rev - I_prev * V_single) * self.lambda_T4.detach()
+        Q_cool = m_prev * 4180.0 * (Tout_prev - Tin_prev) * self.lambda_T1.detach()
+        Q_rad = 20.0 * 0.2 * (Tout_prev - 25.0) * self.lambda_T3.detach()
+        dT = (Q_el - Q_cool - Q_rad) / self.lambda_T2.detach()
+        T_next = Tout_prev + dT * 0.1
+        T_full = torch.cat([T_out[0:1], T_next], dim=0)
+        return T_out - T_full, T_full, T_out
+
+    def aleatoric_loss(self, gt, pred_y, logvar):
+        """01:916-927."""
+        precision = torch.exp(-logvar)
+        loss = torch.mean(0.5 * precision * (gt - pred_y) ** 2 + 0.5 * logvar)
+        return loss + 0.01 * torch.mean(torch.abs(logvar))
+
+    # ------------------------------------------------------------------ trainers
+    def _log(self, *a):
+        if self.verbose and _dp.rank(self._group) == 0:
+            print(*a)
+
+    def _workspace(self, n_rows):
+        if n_rows not in self._work:
+            self._work.clear()
+            wb = self._lib.pinn_train_workspace_bytes(ctypes.byref(self.dnn._net), n_rows)
+            if wb == 0:
+                raise _lib.PinnError("pinn_train_workspace_bytes rejected the network")
+            self._work[n_rows] = torch.empty(wb, dtype=torch.uint8, device=self.x.device)
+        return self._work[n_rows]
+
+    def train_step_grads(self, x, y, row_offset, n_global):
+        """One fused forward + aleatoric_loss + backward on rows (x, y): fills the flat gradient
+        (already divided by n_global) and returns the raw loss sums double[4] on the device."""
+        n = x.shape[0]
+        work = self._workspace(n)
+        self._step_counter += 1
+        training = self.dnn.training and any(m.p > 0 for m in self.dnn.dropout_modules())
+        drop = self.dnn.dropout_struct(self._step_counter, row_offset) if training else None
+        if drop is not None and self.dnn._mask_bits is not None:
+            self.dnn._mask_pass += 1
+        loss = torch.empty(4, dtype=torch.float64, device=x.device)
+        rc = self._lib.pinn_mlp_train_grads(ctypes.byref(self.dnn._net), _ptr(self.dnn.flat_params()), _ptr(x), _ptr(y), n,
+                                            int(n_global), ctypes.byref(drop) if drop else None,
+                                            _ptr(self.dnn._flat_grad), _ptr(loss), _ptr(work), work.numel(), _stream())
+        _lib.check(rc, "pinn_mlp_train_grads")
+        return loss
+
+    def train_dnn(self, nIter, batch_size=None):
+        """01:929-964: Adam(lr=0.01) + StepLR(1000, 0.8) over the 14 weight/bias tensors,
+        full batch (or `batch_size`-row minibatches: one optimizer step each)."""
+        for param in self.dnn.parameters():
+            param.requires_grad = True
+        for n in LAMBDA_NAMES[:4]:
+            getattr(self, n).requires_grad = False
+        self._adam_m.zero_(); self._adam_v.zero_()
+        self._log('================== DNN training ==================')
+        self._log('  Epoch |    Loss    |    MSE     |    LR    ')
+        self.dnn.train()
+        x, y = self.x.detach(), self.u.reshape(-1)
+        n = self.n_local
+        flat, grad = self.dnn.flat_params(), self.dnn._flat_grad
+        step = 0
+        loss_sums = None
+        if batch_size is None or batch_size >= n:
+            batches = [(0, n, self.n_global)]
+        else:       # minibatches: each normalised by its GLOBAL size (sum over ranks)
+            counts = {}
+            batches = []
+            for s in range(0, n, batch_size):
+                e = min(n, s + batch_size)
+                if e - s not in counts:
+                    counts[e - s] = _dp.global_count(e - s, self.x.device, self._group)
+                batches.append((s, e, counts[e - s]))
+        for epoch in range(nIter):
+            lr = 0.01 * 0.8 ** (epoch // 1000)
+            for (s, e, n_norm) in batches:
+                xb, yb = (x, y) if (s, e) == (0, n) else (x[s:e], y[s:e])
+                loss_sums = self.train_step_grads(xb, yb, self.row_offset + s, n_norm)
+                _dp.allreduce_grads(self.dnn._flat_grad_full, loss_sums, self._group)
+                step += 1
+                rc = self._lib.pinn_adam_step(_ptr(flat), _ptr(grad), _ptr(self._adam_m), _ptr(self._adam_v), flat.numel(),
+                                              lr, step, _stream())
+                _lib.check(rc, "pinn_adam_step")
+            if epoch % 1000 == 0:
+                ls = loss_sums.cpu().numpy()
+                lr_next = 0.01 * 0.8 ** ((epoch + 1) // 1000)
+                self._log(f' {epoch:5d}  | {(ls[0] + 0.01 * ls[1]) / n_norm:10.3e} | {ls[2] / n_norm:10.3e} | {lr_next:8.1e}')
+        if loss_sums is not None:
+            ls = loss_sums.cpu().numpy()
+            self.last_loss = (ls[0] + 0.01 * ls[1]) / n_norm
+            self._log(f'DNN training done, final loss: {self.last_loss:.3e}')
+
+    def _run_lambda_stage(self, stage, nIter, flags, lr0, gamma, need_u, log_fn):
+        self.dnn.eval()
+        dev = self.x.device
+        x, y = self.x.detach(), self.u.reshape(-1)
+        aff = self._affine(self.x_scal)
+        u = None
+        if need_u:      # DNN weights are frozen during the stage: one eval forward serves every iteration
+            u = self.dnn(x)[0].reshape(-1)
+        adam = torch.zeros(2 * _lib.NLAMBDA, dtype=torch.float32, device=dev)
+        loss = torch.zeros(2, dtype=torch.float32, device=dev)
+        lam = self._lambdas()
+        for epoch in range(nIter):
+            lr = lr0 * gamma ** (epoch // 1000)
+            rc = self._lib.pinn_residuals(_ptr(x), _ptr(u), _ptr(y), ctypes.byref(aff), _ptr(lam), flags, self.n_local,
+                                          None, 0, _ptr(self._sums), _ptr(self._res_work), self._res_work.numel(), _stream())
+            _lib.check(rc, "pinn_residuals")
+            _dp.allreduce_sums(self._sums, self._group)
+            rc = self._lib.pinn_lambda_step(stage, _ptr(self._sums), self.n_global, aff.vn_scale, lr, epoch + 1, _ptr(lam),
+                                            _ptr(adam), _ptr(loss), _stream())
+            _lib.check(rc, "pinn_lambda_step")
+            if epoch % 1000 == 0:
+                log_fn(epoch, loss.cpu().numpy(), self._sums.cpu().numpy(), lr0 * gamma ** ((epoch + 1) // 1000))
+        self.last_loss = float(loss[0].item()) if nIter > 0 else None
+
+    def _freeze_all_but(self, live):
+        for n in LAMBDA_NAMES:
+            getattr(self, n).requires_grad = n in live
+
+    def train_lambda(self, nIter, dnn_para=False):
+        """01:966-1058."""
+        for param in self.dnn.parameters():
+            param.requires_grad = dnn_para
+        self._freeze_all_but(LAMBDA_NAMES[:4])
+        self._log('================ voltage parameter training ================')
+        self._log('  Epoch | total loss | phys loss |   l1    |    l2     |   l3   |    LR    ')
+
+        def log(epoch, loss, sums, lr):
+            l = self._lambda.cpu().numpy()
+            self._log(f' {epoch:5d}  | {loss[0]:9.3e} | {loss[1]:10.3e} | {l[0]:7.4f} | {l[1]:9.2e} | {l[2]:6.3f} | {lr:8.1e}')
+        self._run_lambda_stage(_lib.STAGE_LAMBDA_F if dnn_para else _lib.STAGE_LAMBDA_PM, nIter, _lib.RES_V, 1e-3, 0.8, True, log)
+
+    def train_thermal(self, nIter):
+        """01:1060-1151."""
+        for param in self.dnn.parameters():
+            param.requires_grad = False
+        self._freeze_all_but(LAMBDA_NAMES[4:9])
+        self._log('---------------- thermal parameter training ----------------')
+        self._log(' Epoch |   Loss    |  MAE(C)  |   T1    |   T2   |   T3   |   T4   |    T5    |    LR   |')
+
+        def log(epoch, loss, sums, lr):
+            l = self._lambda.cpu().numpy()
+            mae = sums[_lib.S["FT_ABS"]] / self.n_global
+            self._log(f' {epoch:3d}   | {loss[0]:9.3e} | {mae:8.2f} | {l[4]:7.4f} | {l[5]:6.3f} | {l[6]:6.3f} | {l[7]:6.2f} | {l[8]:6.2f} |{lr:8.1e}')
+        self._run_lambda_stage(_lib.STAGE_THERMAL, nIter, _lib.RES_T, 1.0, 0.8, False, log)
+
+    def train_hydrogen(self, nIter):
+        """01:1305-1399."""
+        for param in self.dnn.parameters():
+            param.requires_grad = False
+        self._freeze_all_but(LAMBDA_NAMES[9:13])
+        self._log('================ hydrogen parameter training ================')
+        self._log(' Epoch |   Loss    |   actual   |   target   |   H1    |   H2   |   H3   |   H4   |    LR    ')
+
+        def log(epoch, loss, sums, lr):
+            l = self._lambda.cpu().numpy()
+            self._log(f' {epoch:3d}   | {loss[0]:9.3e} | {sums[_lib.S["ACTH"]] / self.n_global:10.3f} | '
+                      f'{sums[_lib.S["TGTH"]] / self.n_global:10.3f} | {l[9]:7.4f} | {l[10]:6.3f} | {l[11]:6.3f} | {l[12]:6.2f} | {lr:8.1e}')
+        self._run_lambda_stage(_lib.STAGE_HYDROGEN, nIter, _lib.RES_H, 1e-1, 0.9, False, log)
+
+    def train_oxygen(self, nIter):
+        """01:1153-1303."""
+        for param in self.dnn.parameters():
+            param.requires_grad = False
+        self._freeze_all_but(LAMBDA_NAMES[13:17])
+        self._log('================ oxygen parameter training ================')
+        self._log(' Epoch |   Loss    |   actual   |   target   |   O1    |   O2   |   O3   |   O4   |    LR    ')
+
+        def log(epoch, loss, sums, lr):
+            l = self._lambda.cpu().numpy()
+            self._log(f' {epoch:3d}   | {loss[0]:6.3e} | {sums[_lib.S["ACTO"]] / self.n_global:6.3f} | '
+                      f'{sums[_lib.S["TGTO"]] / self.n_global:6.3f} | {l[13]:7.2f} | {l[14]:6.3f} | {abs(l[15]):6.1f}A | {l[16]:5.2f} | {lr:8.1e}')
+        self._run_lambda_stage(_lib.STAGE_OXYGEN, nIter, _lib.RES_O, 1e-2, 0.9, False, log)
+
+    def predict(self, X, x_scal):
+        """01:1401-1410: (u [N,1], log_var [N,1]) numpy, in the caller's train/eval mode.
+        (The reference's discarded `net_f_V` call, 01:1407, is not run.)"""
+        x = self._dev_rows(X)
+        u, log_var = self.net_u(x)
+        return u.detach().cpu().numpy(), log_var.detach().cpu().numpy()
+
+    # ------------------------------------------------------------------ MC-dropout (used by mc.get_MC_samples)
+    def mc_dropout(self, X, mc_times, row_offset=0):
+        """1 eval pass + mc_times stochastic passes in one persistent launch -> three [N] device tensors."""
+        x = self._dev_rows(X)
+        n = x.shape[0]
+        out = torch.empty(3, n, device=x.device, dtype=torch.float32)
+        self._mc_calls = getattr(self, "_mc_calls", 0) + 1
+        drop = self.dnn.dropout_struct(0xC0000000 + (self._mc_calls << 16), row_offset)
+        rc = self._lib.pinn_mc_dropout(ctypes.byref(self.dnn._net), _ptr(self.dnn.flat_params()), _ptr(x), n, ctypes.byref(drop),
+                                       int(mc_times), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _stream())
+        _lib.check(rc, "pinn_mc_dropout")
+        return out[0], out[1], out[2]

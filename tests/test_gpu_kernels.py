@@ -1,0 +1,199 @@
+"""GPU parity of the forward / MC-dropout / residual kernels through the C ABI, against the
+reference's golden vectors (tests/golden, made by oracle/make_golden.py) and the CPU oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import pinn_oracle as O
+from conftest import ScalerFromArrays, load_golden, params_from_golden, unpack_mask
+
+ATOL = RTOL = 1e-5      # fp32 path tolerance on forward / residual values
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pinn_amd import _lib
+    return _lib.load()
+
+
+@pytest.mark.parametrize("fname,H", [("g_net128.npz", 128), ("g_net256.npz", 256)])
+def test_forward_golden_eval_and_recorded_masks(lib, fname, H):
+    import hip_helpers as hh
+    g = load_golden(fname)
+    P = params_from_golden(g)
+    fp = hh.flat_params(P, H, 3).to(hh.dev())
+    x = torch.from_numpy(g["x"]).to(hh.dev())
+    u, lv = hh.forward(lib, H, 3, fp, x)
+    np.testing.assert_allclose(u.cpu().numpy(), g["eval_u"].reshape(-1), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(lv.cpu().numpy(), g["eval_logvar"].reshape(-1), rtol=RTOL, atol=ATOL)
+    for p in (0.2, 0.4):
+        for t in range(2):
+            tag = "p%.1f_t%d" % (p, t)
+            masks = [unpack_mask(g["mask%d_%s" % (l, tag)], H if l < 3 else H // 2) for l in range(4)]
+            bits = hh.pack_mask_bits([masks]).to(hh.dev())
+            u, lv = hh.forward(lib, H, 3, fp, x, hh.dropout_struct(2, [p] * 4, bits=bits))
+            np.testing.assert_allclose(u.cpu().numpy(), g["sto_u_" + tag].reshape(-1), rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(lv.cpu().numpy(), g["sto_logvar_" + tag].reshape(-1), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("H,nh,N", [(256, 3, 1), (256, 3, 127), (128, 1, 130), (128, 5, 1000), (256, 4, 4097)])
+def test_forward_philox_vs_oracle_ragged(lib, H, nh, N):
+    """Philox masks generated on chip == the oracle's specification, for ragged row counts / depths."""
+    import hip_helpers as hh
+    from pinn_amd import synth
+    P = O.init_params([8] + [H] * nh + [1], seed=N)
+    x = synth.make_dataset(max(N, 2), (), seed=N)[0][:N].contiguous()
+    fp = hh.flat_params(P, H, nh).to(hh.dev())
+    pl = [0.1 + 0.1 * (l % 4) for l in range(nh + 1)]
+    seed, stream, row0 = (1 << 40) + 17, 0xFFFFFFF0, (1 << 33) + 5
+    xd = x.to(hh.dev())
+    u, lv = hh.forward(lib, H, nh, fp, xd, hh.dropout_struct(1, pl, seed=seed, stream_id=stream, row_offset=row0))
+    masks = O.philox_masks_for_net(seed, stream, row0, N, H, nh, pl)
+    with torch.no_grad():
+        uo, lvo = O.mlp_forward(P, x, pl, masks)
+    np.testing.assert_allclose(u.cpu().numpy(), uo.numpy().reshape(-1), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(lv.cpu().numpy(), lvo.numpy().reshape(-1), rtol=RTOL, atol=ATOL)
+
+
+def test_forward_empty_and_bad_args(lib):
+    import hip_helpers as hh
+    from pinn_amd import _lib
+    net = _lib.Net(8, 256, 3)
+    fp = torch.zeros(lib.pinn_param_count(ctypes.byref(net)), device=hh.dev())
+    x = torch.zeros(0, 8, device=hh.dev())
+    u = torch.zeros(1, device=hh.dev())
+    assert lib.pinn_mlp_forward(ctypes.byref(net), hh.ptr(fp), hh.ptr(x), 0, None, hh.ptr(u), hh.ptr(u), hh.stream()) == 0
+    assert lib.pinn_mlp_forward(ctypes.byref(net), None, hh.ptr(x), 0, None, hh.ptr(u), hh.ptr(u), hh.stream()) == -1
+    bad = _lib.Net(8, 96, 3)
+    assert lib.pinn_mlp_forward(ctypes.byref(bad), hh.ptr(fp), hh.ptr(x), 0, None, hh.ptr(u), hh.ptr(u), hh.stream()) == -2
+    assert lib.pinn_param_count(ctypes.byref(bad)) == -2
+
+
+def test_mc_dropout_golden_recorded_masks(lib):
+    """G8: get_MC_samples of the reference (T=4), masks replayed."""
+    import hip_helpers as hh
+    from pinn_amd import _lib
+    g = load_golden("g_mc.npz")
+    P = params_from_golden(g)
+    x = torch.from_numpy(g["x"]).to(hh.dev())
+    N = x.shape[0]
+    per_pass = [[unpack_mask(g["mask%d_t%d" % (l, t)], 128 if l < 3 else 64) for l in range(4)] for t in range(4)]
+    bits = hh.pack_mask_bits(per_pass).to(hh.dev())
+    out = torch.empty(3, N, device=hh.dev())
+    net = _lib.Net(8, 128, 3)
+    d = hh.dropout_struct(2, [0.4] * 4, bits=bits)
+    fp = hh.flat_params(P, 128, 3).to(hh.dev())
+    _lib.check(lib.pinn_mc_dropout(ctypes.byref(net), hh.ptr(fp), hh.ptr(x), N, ctypes.byref(d), 4,
+                                   hh.ptr(out[0]), hh.ptr(out[1]), hh.ptr(out[2]), hh.stream()), "mc")
+    o = out.cpu().numpy()
+    np.testing.assert_allclose(o[0], g["pred_mean"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(o[1], g["a_u"], rtol=1e-5)
+    np.testing.assert_allclose(o[2], g["e_u"], rtol=1e-4, atol=1e-6)
+
+
+def test_mc_dropout_philox_statistics(lib):
+    """T=256 on-chip Philox passes vs the oracle run on the SAME masks (exact spec), plus the
+    statistical band vs torch-bernoulli masks: rel. s.e. of a std estimate ~ 1/sqrt(2T)."""
+    import hip_helpers as hh
+    from pinn_amd import _lib, synth
+    H, nh, N, T, p = 256, 3, 200, 64, 0.4
+    P = O.init_params([8, H, H, H, 1], seed=1)
+    x = synth.make_dataset(N, (), seed=2)[0]
+    out = torch.empty(3, N, device=hh.dev())
+    net = _lib.Net(8, H, nh)
+    d = hh.dropout_struct(1, [p] * 4, seed=99, stream_id=1000, row_offset=0)
+    fp, xd = hh.flat_params(P, H, nh).to(hh.dev()), x.to(hh.dev())      # keep the device buffers alive across the launch
+    _lib.check(lib.pinn_mc_dropout(ctypes.byref(net), hh.ptr(fp), hh.ptr(xd), N,
+                                   ctypes.byref(d), T, hh.ptr(out[0]), hh.ptr(out[1]), hh.ptr(out[2]), hh.stream()), "mc")
+    o = out.cpu().numpy()
+    pm, au, eu = O.mc_dropout(P, x, p, T, lambda t: O.philox_masks_for_net(99, 1000 + t, 0, N, H, nh, [p] * 4))
+    np.testing.assert_allclose(o[0], pm, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(o[1], au, rtol=1e-5)
+    np.testing.assert_allclose(o[2], eu, rtol=1e-4, atol=1e-6)
+    # independent torch-bernoulli masks (what the reference draws): agreement within Monte-Carlo error
+    gen = torch.Generator().manual_seed(0)
+    mk = lambda t: [(torch.rand(N, w, generator=gen) >= p).numpy() for w in (H, H, H, H // 2)]
+    _, au2, eu2 = O.mc_dropout(P, x, p, T, mk)
+    assert abs(np.mean(o[2]) / np.mean(eu2) - 1) < 4 / np.sqrt(2 * T)
+    assert abs(np.mean(o[1]) / np.mean(au2) - 1) < 0.05
+
+
+@pytest.mark.parametrize("si", [0, 1])
+def test_residuals_golden(lib, si):
+    """G5: every tuple element of net_f_V/_T_simple/_H/_O + d mean(f^2)/d lambda on branch-edge rows."""
+    import hip_helpers as hh
+    from pinn_amd import _lib
+    g = load_golden("g_resid.npz")
+    sx, sy = ScalerFromArrays(g, "sx."), ScalerFromArrays(g, "sy.")
+    aff = hh.affine_struct(sx, sy)
+    N = g["x"].shape[0]
+    x = torch.from_numpy(g["x"]).to(hh.dev())
+    u = torch.from_numpy(g["u_eval"]).reshape(-1).to(hh.dev())
+    y = torch.from_numpy(g["y"]).reshape(-1).to(hh.dev())
+    lam = torch.tensor(g["s%d.lambdas" % si], dtype=torch.float32).to(hh.dev())
+    cols = torch.zeros(_lib.NCOLS, N, device=hh.dev())
+    sums = torch.zeros(_lib.NSUMS, dtype=torch.float64, device=hh.dev())
+    wb = lib.pinn_residuals_workspace_bytes()
+    work = torch.empty(wb, dtype=torch.uint8, device=hh.dev())
+    _lib.check(lib.pinn_residuals(hh.ptr(x), hh.ptr(u), hh.ptr(y), ctypes.byref(aff), hh.ptr(lam), _lib.RES_ALL, N, hh.ptr(cols), N,
+                                  hh.ptr(sums), hh.ptr(work), wb, hh.stream()), "residuals")
+    c, s = cols.cpu().numpy(), sums.cpu().numpy()
+    C, S = _lib.C, _lib.S
+    pairs = [("V", 0, "FV"), ("V", 1, "VACT"), ("V", 2, "VOHM"), ("V", 3, "VCONC"), ("V", 4, "ENERNST"), ("V", 5, "VEST5"), ("V", 6, "I"),
+             ("V", 8, "VOUT5"), ("T", 0, "FT"), ("T", 1, "TPRED"), ("T", 2, "TOUT"), ("H", 0, "FH"), ("H", 1, "ACTH"), ("H", 2, "TGTH"),
+             ("H", 3, "ITOT"), ("O", 0, "FO"), ("O", 1, "ACTO"), ("O", 2, "TGTO"), ("O", 3, "QO2"), ("O", 4, "O2FLOW")]
+    for tag, j, cn in pairs:
+        want = g["s%d.%s.%d" % (si, tag, j)].reshape(-1)
+        np.testing.assert_allclose(c[C[cn]], want, rtol=RTOL, atol=ATOL * max(1.0, np.abs(want).max()), err_msg=cn)
+    # the elementwise T/H/O models carry no transcendental: bit-exact with the reference
+    for tag, j, cn in pairs:
+        if tag in "THO":
+            assert np.array_equal(c[C[cn]], g["s%d.%s.%d" % (si, tag, j)].reshape(-1)), cn
+    L = O.LAMBDA_NAMES.index
+    checks = [("V", "FV2", [("FV_D1", "lambda_1"), ("FV_D2", "lambda_2"), ("FV_D3", "lambda_3")]),
+              ("T", "FT2", [("FT_D1", "lambda_T1"), ("FT_D3", "lambda_T3"), ("FT_D5", "lambda_T5")]),
+              ("H", "FH2", [("FH_D1", "lambda_H1"), ("FH_D2", "lambda_H2"), ("FH_D3", "lambda_H3")]),
+              ("O", "FO2", [("FO_D1", "lambda_O1"), ("FO_D2", "lambda_O2"), ("FO_D3", "lambda_O3")])]
+    for tag, lossn, grads in checks:
+        assert abs(s[S[lossn]] / N - g["s%d.%s.loss" % (si, tag)]) <= 1e-5 * abs(g["s%d.%s.loss" % (si, tag)])
+        for sn, ln in grads:
+            want = g["s%d.%s.grad" % (si, tag)][L(ln)]
+            assert abs(2 * s[S[sn]] / N - want) <= 1e-4 * abs(want) + 1e-9, (sn, 2 * s[S[sn]] / N, want)
+    # train_lambda(dnn_para=False): loss mean((y - Vn)^2) and its gradient -(2/N) 5 s_y sum (y-Vn) df/dlambda
+    assert abs(s[S["YV2"]] / N - g["s%d.Vn.loss" % si]) <= 1e-5 * abs(g["s%d.Vn.loss" % si])
+    for k, ln in enumerate(("lambda_1", "lambda_2", "lambda_3")):
+        want = g["s%d.Vn.grad" % si][L(ln)]
+        got = -2.0 * 5.0 * aff.vn_scale * s[S["YV_D1"] + k] / N
+        assert abs(got - want) <= 1e-4 * abs(want) + 1e-9, (ln, got, want)
+
+
+def test_residuals_partial_flags_and_determinism(lib):
+    import hip_helpers as hh
+    from pinn_amd import _lib, synth
+    N = 100003
+    ds = synth.make_dataset(N, (), seed=4)
+    aff = hh.affine_struct(ds[4], ds[5])
+    x = ds[0].to(hh.dev())
+    lam = torch.tensor(O.LAMBDA_INIT and [O.LAMBDA_INIT[n] for n in O.LAMBDA_NAMES], dtype=torch.float32).to(hh.dev())
+    wb = lib.pinn_residuals_workspace_bytes()
+    work = torch.empty(wb, dtype=torch.uint8, device=hh.dev())
+    outs = []
+    for rep in range(2):
+        sums = torch.zeros(_lib.NSUMS, dtype=torch.float64, device=hh.dev())
+        _lib.check(lib.pinn_residuals(hh.ptr(x), None, None, ctypes.byref(aff), hh.ptr(lam), _lib.RES_T | _lib.RES_H | _lib.RES_O, N,
+                                      None, 0, hh.ptr(sums), hh.ptr(work), wb, hh.stream()), "residuals")
+        outs.append(sums.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert outs[0][_lib.S["FV2"]] == 0.0 and outs[0][_lib.S["FT2"]] > 0
+    # voltage residual without u is an argument error
+    assert lib.pinn_residuals(hh.ptr(x), None, None, ctypes.byref(aff), hh.ptr(lam), _lib.RES_V, N, None, 0, None, None, 0, hh.stream()) == -1
+    # oracle agreement of the sums at this size
+    real = torch.from_numpy(O.denorm(ds[0].numpy(), *O.scaler_affine(ds[4])))
+    lamo = O.init_lambdas()
+    for fn, key in ((O.net_f_T_simple, "FT2"), (O.net_f_H, "FH2"), (O.net_f_O, "FO2")):
+        want = float((fn(real, lamo)[0].double() ** 2).sum())
+        assert abs(outs[0][_lib.S[key]] - want) <= 1e-5 * abs(want)

@@ -36,7 +36,8 @@ def test_golden_loss_and_grads_recorded_masks(lib):
     masks = [unpack_mask(g["mask%d_p0.2_t0" % l], 128 if l < 3 else 64) for l in range(4)]
     bits = hh.pack_mask_bits([masks]).to(hh.dev())
     drop = hh.dropout_struct(2, [0.2] * 4, bits=bits)
-    grads, loss = hh.train_grads(lib, 128, 3, hh.flat_params(P, 128, 3).to(hh.dev()), x.to(hh.dev()), y.to(hh.dev()), drop)
+    fp, xd, yd = hh.flat_params(P, 128, 3).to(hh.dev()), x.to(hh.dev()), y.to(hh.dev())
+    grads, loss = hh.train_grads(lib, 128, 3, fp, xd, yd, drop)
     N = x.shape[0]
     l = loss.cpu().numpy()
     total = l[0] / N + 0.01 * l[1] / N
@@ -54,8 +55,8 @@ def test_grads_vs_oracle_autograd(lib, H, nh, N, mode):
     pl = [0.2] * (nh + 1)
     seed, stream, row0 = 987654321987, 42, 12345
     drop = hh.dropout_struct(mode, pl, seed=seed, stream_id=stream, row_offset=row0)
-    grads, loss = hh.train_grads(lib, H, nh, hh.flat_params(P, H, nh).to(hh.dev()), x.to(hh.dev()).contiguous(),
-                                 y.to(hh.dev()).contiguous(), drop)
+    fp, xd, yd = hh.flat_params(P, H, nh).to(hh.dev()), x.to(hh.dev()).contiguous(), y.to(hh.dev()).contiguous()
+    grads, loss = hh.train_grads(lib, H, nh, fp, xd, yd, drop)
     masks = O.philox_masks_for_net(seed, stream, row0, N, H, nh, pl) if mode == 1 else None
     lo, mse, go, _, _ = O.nll_loss_and_grads(P, x, ds[1], pl, masks)
     l = loss.cpu().numpy()
