@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""bench.py -- PINN training samples/s (+ MC-dropout forward-passes/s) on synthetic 1e6 x 8 rows.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: reference architecture [8,256,256,256,1] (p=0.2, variance
+head), ROWS_PER_GPU synthetic fuel-cell rows per GPU resident in HBM, fp32 (exact fp32 MFMA).
+One timed "step" advances EVERY trainer of the reference once over those rows:
+   train_dnn step   : fused forward + aleatoric NLL + backward + weight gradients
+                      + RCCL all-reduce(SUM) of the flat gradient bucket (N > 1) + Adam
+   physics stages   : one iteration each of train_lambda(False), train_lambda(True),
+                      train_thermal, train_hydrogen, train_oxygen
+                      (fused residual pass -> [all-reduce of 32 sums] -> Adam + clamp on device)
+value = rows of all ranks * steps / max-over-ranks wall time (weak scaling: rows per GPU fixed).
+
+Extra legs reported in the same JSON line (rank 0):
+   mc_dropout   : get_MC_samples-equivalent launch (1 eval + T stochastic passes, on-chip reduce)
+   roofline     : dominant kernel (forward+backward chain) timed alone with events on the launch
+                  stream; algorithmic FLOP per row = 4*M - 4096 (forward 2M + dgrad 2(M - 8H)),
+                  M = 174 400 MAC, against the 157.3 TFLOP/s fp32-MFMA peak
+   cpu_baseline : the CPU oracle's train_dnn step (torch CPU, autograd, torch-bernoulli masks,
+                  Adam) on a bounded row sample, host cores of this box (N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, NH = 256, 3
+M_MAC = 8 * H + (NH - 1) * H * H + H + H * H // 2 + H * H // 8 + H // 4        # 174 400
+CHAIN_FLOP_PER_ROW = 4 * M_MAC - 2 * 2 * 8 * H                                 # fwd 2M + dgrad 2(M - 8H)
+STEP_FLOP_PER_ROW = 6 * M_MAC
+FWD_FLOP_PER_ROW = 2 * M_MAC
+PEAK_FP32_MFMA_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1_000_000, help="rows per GPU")
+    ap.add_argument("--mc-passes", type=int, default=512)
+    ap.add_argument("--no-mc", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=100_000)
+    return ap.parse_args()
+
+
+def cpu_baseline(rows):
+    """CPU oracle train_dnn step (the reference's arithmetic, restated) on `rows` rows."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pinn_oracle as O
+    from pinn_amd import synth
+    ds = synth.make_dataset(rows, (), seed=0)
+    x, y = ds[0], ds[1]
+    P = O.init_params([8, H, H, H, 1], seed=0)
+    opt = O.AdamState(P)
+    gen = torch.Generator().manual_seed(0)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        masks = [(torch.rand(rows, w, generator=gen) >= 0.2) for w in (H, H, H, H // 2)]   # bernoulli draws, as the reference pays
+        _, _, grads, _, _ = O.nll_loss_and_grads(P, x, y, [0.2] * 4, masks)
+        opt.step(P, grads, 0.01)
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    # stochastic forward (MC-dropout unit of work)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for t in range(2):
+            masks = [(torch.rand(rows, w, generator=gen) >= 0.4) for w in (H, H, H, H // 2)]
+            O.mlp_forward(P, x, [0.4] * 4, masks)
+    fwd = (time.perf_counter() - t0) / 2
+    return {"value": rows / best, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "train_dnn step (fwd+NLL+autograd bwd+Adam, torch-bernoulli masks) of oracle/pinn_oracle.py on %d rows, "
+                      "best of 2 after 1 warm-up; os.cpu_count()=%d" % (rows, os.cpu_count()),
+            "mc_fwd_passes_per_s": rows / fwd}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import pinn_amd
+    from pinn_amd import _lib, synth
+
+    rows = args.rows
+    n_global = rows * world
+    # synthetic rows: every rank draws its own shard (seed = rank) and all ranks share rank 0's scalers
+    ds0 = synth.make_dataset(4096, (), seed=12345)
+    sx, sy = ds0[4], ds0[5]
+    Xp, Up = synth.synth_rows(rows, seed=1000 + rank)
+    x = torch.from_numpy(sx.transform(Xp).astype("float32"))
+    y = torch.from_numpy(sy.transform(Up).astype("float32"))
+    torch.manual_seed(0)                               # identical initial weights on every rank
+    model = pinn_amd.PhysicsInformedNN(x, y, [8, H, H, H, 1], sx, sy, p=0.2, logvar=True, seed=0,
+                                       row_offset=rank * rows, n_global=n_global)
+    model.verbose = False
+    model.dnn.train()
+    lib = model._lib
+    import ctypes
+    from pinn_amd.model import _ptr, _stream
+    from pinn_amd import dp
+
+    xd, yd = model.x.detach(), model.u.reshape(-1)
+    flat = model.dnn.flat_params()
+    aff = model._affine(sx)
+    u_eval = torch.zeros(rows, device=dev)
+    adam_l = torch.zeros(2 * _lib.NLAMBDA, device=dev)
+    loss_l = torch.zeros(2, device=dev)
+    stages = [(_lib.STAGE_LAMBDA_PM, _lib.RES_V, 1e-3), (_lib.STAGE_LAMBDA_F, _lib.RES_V, 1e-3),
+              (_lib.STAGE_THERMAL, _lib.RES_T, 1.0), (_lib.STAGE_HYDROGEN, _lib.RES_H, 1e-1), (_lib.STAGE_OXYGEN, _lib.RES_O, 1e-2)]
+    step_no = [0]
+
+    def one_step():
+        step_no[0] += 1
+        # ---- train_dnn step (01:949-955)
+        loss = model.train_step_grads(xd, yd, model.row_offset, n_global)
+        dp.allreduce_grads(model.dnn._flat_grad_full, loss, model._group)
+        _lib.check(lib.pinn_adam_step(_ptr(flat), _ptr(model.dnn._flat_grad), _ptr(model._adam_m), _ptr(model._adam_v),
+                                      flat.numel(), 0.01, step_no[0], _stream()), "adam")
+        # ---- one iteration of each physics-parameter stage (01:1008-1055, 1107-1151, 1354-1391, 1204-1274)
+        lam = model._lambdas()
+        for stage, flags, lr in stages:
+            _lib.check(lib.pinn_residuals(_ptr(xd), _ptr(u_eval), _ptr(yd), ctypes.byref(aff), _ptr(lam), flags, rows, None, 0,
+                                          _ptr(model._sums), _ptr(model._res_work), model._res_work.numel(), _stream()), "residuals")
+            dp.allreduce_sums(model._sums, model._group)
+            _lib.check(lib.pinn_lambda_step(stage, _ptr(model._sums), n_global, aff.vn_scale, lr, step_no[0], _ptr(lam), _ptr(adam_l),
+                                            _ptr(loss_l), _stream()), "lambda_step")
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # the eval forward that feeds net_f_V (weights frozen within a lambda stage: once per stage call)
+    model.dnn.eval(); u_eval.copy_(model.dnn(xd)[0].reshape(-1)); model.dnn.train()
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_global * args.steps / elapsed
+    final_loss = float((loss[0] + 0.01 * loss[1]).item() / n_global)
+
+    out = {
+        "metric": "pinn_train_samples_per_s", "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: %d synthetic rows x 8 features per GPU, PINN [8,256,256,256,1] + variance head, "
+                               "step = train_dnn (fwd+NLL+bwd+wgrad+allreduce+Adam) + one iteration of each of the 5 physics stages"
+                               % rows,
+                   "rows_per_gpu": rows, "global_rows": n_global, "parallelism": "dp%d" % world, "final_loss": final_loss},
+    }
+
+    # ------------------------------------------------------------------ roofline leg (rank 0 kernel, events on the launch stream)
+    def time_events(fn, reps):
+        fn(); torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(reps):
+            fn()
+        ev1.record(); torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / reps     # ms
+
+    work = model._workspace(rows)
+    drop = model.dnn.dropout_struct(7, model.row_offset)
+    loss_buf = torch.empty(4, dtype=torch.float64, device=dev)
+
+    def phase(ph):
+        return lambda: _lib.check(lib.pinn_mlp_train_grads_phases(
+            ctypes.byref(model.dnn._net), _ptr(flat), _ptr(xd), _ptr(yd), rows, n_global, ctypes.byref(drop), _ptr(model.dnn._flat_grad),
+            _ptr(loss_buf), _ptr(work), work.numel(), _stream(), ph), "phases")
+    reps = max(3, min(10, args.steps))
+    ms_chain = time_events(phase(1), reps)
+    ms_wgrad = time_events(phase(2), reps)
+    ms_reduce = time_events(phase(4), reps)
+    achieved = CHAIN_FLOP_PER_ROW * rows / (ms_chain * 1e-3) / 1e12
+    out["roofline"] = {"kernel": "train_chain_kernel<256>", "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                       "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                       "flop_per_row": CHAIN_FLOP_PER_ROW, "ms": ms_chain,
+                       "wgrad": {"ms": ms_wgrad, "achieved": FWD_FLOP_PER_ROW * rows / (ms_wgrad * 1e-3) / 1e12,
+                                 "frac": FWD_FLOP_PER_ROW * rows / (ms_wgrad * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+                       "reduce_ms": ms_reduce,
+                       "step_mfma_frac": STEP_FLOP_PER_ROW * rows / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                       "hbm_algorithmic_GBps": 36.0 * rows / (ms_per_step * 1e-3) / 1e9}
+
+    # ------------------------------------------------------------------ MC-dropout leg
+    if not args.no_mc:
+        T = args.mc_passes
+        for m in model.dnn.dropout_modules():
+            m.p = 0.4
+        model.dnn.train()
+        model.mc_dropout(xd[:4096], 2); barrier()
+        t0 = time.perf_counter()
+        pm, au, eu = model.mc_dropout(xd, T, row_offset=model.row_offset)
+        barrier()
+        mc_s = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([mc_s], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            mc_s = float(t.item())
+        mc_tf = FWD_FLOP_PER_ROW * rows * (T + 1) / mc_s / 1e12
+        out["mc_dropout"] = {"metric": "mc_dropout_fwd_passes_per_s", "value": n_global * T / mc_s, "unit": "fwd-passes/s",
+                             "rows_per_gpu": rows, "passes": T, "seconds": mc_s,
+                             "roofline": {"kernel": "mlp_kernel<256,MC>", "bound": "mfma", "achieved": mc_tf, "peak": PEAK_FP32_MFMA_TFLOPS,
+                                          "unit": "TFLOP/s", "frac": mc_tf / PEAK_FP32_MFMA_TFLOPS,
+                                          "hbm_algorithmic_GBps": 44.0 * rows / mc_s / 1e9},
+                             "e_u_mean": float(eu.mean().item())}
+        for m in model.dnn.dropout_modules():
+            m.p = 0.2
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_rows)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

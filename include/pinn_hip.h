@@ -161,6 +161,17 @@ int pinn_mlp_train_grads(const pinn_net_t* net, const float* d_params, const flo
                          long long n_rows, long long n_global, const pinn_dropout_t* drop,
                          float* d_grads, double* d_loss, void* d_work, size_t work_bytes, void* stream);
 
+/* The same call restricted to a subset of its kernel launches, so a benchmark can bracket one
+ * kernel with events (bench.py's roofline leg).  phases = PINN_PHASE_ALL is pinn_mlp_train_grads. */
+#define PINN_PHASE_CHAIN 1u   /* forward + loss + backward chain kernel (writes the activation stash) */
+#define PINN_PHASE_WGRAD 2u   /* the per-layer weight-gradient kernels (read the stash)              */
+#define PINN_PHASE_REDUCE 4u  /* fixed-order slab reduction -> d_grads, d_loss                       */
+#define PINN_PHASE_ALL 7u
+int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y,
+                                long long n_rows, long long n_global, const pinn_dropout_t* drop,
+                                float* d_grads, double* d_loss, void* d_work, size_t work_bytes, void* stream,
+                                unsigned phases);
+
 /* torch.optim.Adam defaults (01:939): flat vectors of n floats; step is 1-based. */
 int pinn_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, long long n,
                    float lr, int step, void* stream);

@@ -59,6 +59,8 @@ _SIGS = {
     "pinn_train_workspace_bytes": (c_size_t, [ctypes.POINTER(Net), c_ll]),
     "pinn_mlp_train_grads": (c_int, [ctypes.POINTER(Net), c_void_p, c_void_p, c_void_p, c_ll, c_ll, ctypes.POINTER(Dropout),
                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pinn_mlp_train_grads_phases": (c_int, [ctypes.POINTER(Net), c_void_p, c_void_p, c_void_p, c_ll, c_ll, ctypes.POINTER(Dropout),
+                                            c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_uint]),
     "pinn_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_int, c_void_p]),
 }
 
@@ -74,6 +76,10 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported BEFORE the library: torch bundles its own HIP runtime (libamdhip64.so.7);
+    # loading ours first would pull /opt/rocm's copy as a second runtime, and streams / device
+    # pointers from torch are meaningless to a different runtime instance (hipErrorNoDevice).
+    import torch  # noqa: F401
     path = _build.LIB
     if build_if_missing:
         try:

@@ -166,6 +166,7 @@ static int launch(const pinn_net_t* net, const FwdArgs& a, void* stream) {
   const long long n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
   if (n_tiles == 0) return PINN_OK;
   const int grid = (int)(n_tiles < num_cus() ? n_tiles : num_cus());
+  (void)hipGetLastError();   // drop a stale error left by another HIP user of this thread
   if (net->hidden == 256)
     hipLaunchKernelGGL((mlp_kernel<256, MC>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
   else

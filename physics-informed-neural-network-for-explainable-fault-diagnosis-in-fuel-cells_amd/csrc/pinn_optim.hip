@@ -34,6 +34,7 @@ extern "C" int pinn_adam_step(float* d_params, const float* d_grads, float* d_m,
   const float bc2_sqrt = (float)sqrt(bc2);
   long long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
+  (void)hipGetLastError();   // drop a stale error left by another HIP user of this thread
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_params, d_grads, d_m, d_v, n,
                      step_size, bc2_sqrt);
   hipError_t e = hipGetLastError();

@@ -315,6 +315,7 @@ extern "C" int pinn_residuals(const float* d_x, const float* d_u, const float* d
   if (d_cols && ld < n_rows) return PINN_E_ARG;
   if (d_sums && (!d_work || work_bytes < pinn_residuals_workspace_bytes())) return PINN_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  (void)hipGetLastError();   // drop a stale error left by another HIP user of this thread
   AffineDev a;
   for (int c = 0; c < 8; ++c) { a.x_min[c] = aff->x_min[c]; a.x_scale[c] = aff->x_scale[c]; }
   a.y_min = aff->y_min; a.y_scale = aff->y_scale; a.vn_scale = aff->vn_scale; a.vn_min = aff->vn_min;
@@ -338,6 +339,7 @@ extern "C" int pinn_lambda_step(int stage, const double* d_sums, long long n_glo
                                 float* d_lambda, float* d_adam, float* d_loss, void* stream) {
   if (stage < 0 || stage > PINN_STAGE_OXYGEN || !d_sums || n_global <= 0 || step < 1 || !d_lambda || !d_adam)
     return PINN_E_ARG;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(lambda_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stage, d_sums, 1.0 / (double)n_global,
                      vn_scale, lr, step, d_lambda, d_adam, d_loss);
   hipError_t e = hipGetLastError();

@@ -513,15 +513,16 @@ extern "C" size_t pinn_train_workspace_bytes(const pinn_net_t* net, long long n_
   return plan_workspace(net, n_rows).total;
 }
 
-extern "C" int pinn_mlp_train_grads(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y,
-                                    long long n_rows, long long n_global, const pinn_dropout_t* drop, float* d_grads,
-                                    double* d_loss, void* d_work, size_t work_bytes, void* stream) {
+extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y,
+                                           long long n_rows, long long n_global, const pinn_dropout_t* drop, float* d_grads,
+                                           double* d_loss, void* d_work, size_t work_bytes, void* stream, unsigned phases) {
   int rc = check_net_t(net);
   if (rc) return rc;
   if (!d_params || !d_x || !d_y || !d_grads || !d_loss || !d_work || n_rows <= 0 || n_global < n_rows) return PINN_E_ARG;
   const Workspace w = plan_workspace(net, n_rows);
   if (work_bytes < w.total) return PINN_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  (void)hipGetLastError();   // drop a stale error left by another HIP user of this thread
   char* base = (char*)d_work;
   const int H = net->hidden, nh = net->n_hidden;
   ParamLayout L{H, nh};
@@ -560,14 +561,17 @@ extern "C" int pinn_mlp_train_grads(const pinn_net_t* net, const float* d_params
   const long long n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   int grid = (int)(n_tiles < cu_count() ? n_tiles : cu_count());
   if (grid > 1024) grid = 1024;
-  if (H == 256) hipLaunchKernelGGL((train_chain_kernel<256>), dim3(grid), dim3(kThreads), 0, st, a);
-  else hipLaunchKernelGGL((train_chain_kernel<128>), dim3(grid), dim3(kThreads), 0, st, a);
+  if (phases & PINN_PHASE_CHAIN) {
+    if (H == 256) hipLaunchKernelGGL((train_chain_kernel<256>), dim3(grid), dim3(kThreads), 0, st, a);
+    else hipLaunchKernelGGL((train_chain_kernel<128>), dim3(grid), dim3(kThreads), 0, st, a);
+  }
 
   float* slabs = (float*)(base + w.off_slabs);
   const long long tot = L.total();
   const long long hs = (long long)w.t32 * H * 32;   // floats per hidden-layer stash
   WgradArgs g{};
   g.x = d_x; g.n_rows = n_rows; g.t32 = w.t32; g.n_slices = w.n_slices; g.slab_stride = tot;
+  if (phases & PINN_PHASE_WGRAD) {
   // layer 0: dW0 = dpre_0 x^T
   g.P = a.dpre_h; g.Q = nullptr; g.OUT = H; g.IN = 8; g.dW = slabs + L.w0(); g.db = slabs + L.b0();
   g.s1 = nullptr; g.dvq = nullptr; g.s2 = nullptr; g.R = nullptr; g.dvr = nullptr;
@@ -584,9 +588,18 @@ extern "C" int pinn_mlp_train_grads(const pinn_net_t* net, const float* d_params
   g.P = a.dpre_v2; g.Q = a.stash_v1; g.OUT = H / 4; g.IN = H / 2; g.dW = slabs + L.wv1(); g.db = slabs + L.bv1();
   g.s1 = nullptr; g.dvq = nullptr; g.s2 = a.dz; g.R = a.stash_v2; g.dvr = slabs + L.wv2();
   if ((rc = dispatch_wgrad(g, st))) return rc;
+  }
 
+  if (phases & PINN_PHASE_REDUCE)
   hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, slabs, w.n_slices, tot,
                      a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;
+}
+
+extern "C" int pinn_mlp_train_grads(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y,
+                                    long long n_rows, long long n_global, const pinn_dropout_t* drop, float* d_grads,
+                                    double* d_loss, void* d_work, size_t work_bytes, void* stream) {
+  return pinn_mlp_train_grads_phases(net, d_params, d_x, d_y, n_rows, n_global, drop, d_grads, d_loss, d_work, work_bytes,
+                                     stream, PINN_PHASE_ALL);
 }

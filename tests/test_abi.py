@@ -1,0 +1,72 @@
+"""CPU: the C-ABI library builds for gfx950, loads without a GPU and exports every symbol that
+include/pinn_hip.h declares; host-only entry points behave (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from pinn_amd import _lib
+    return _lib.load(build_if_missing=False)
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "pinn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pinn_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound(lib):
+    from pinn_amd import _lib
+    names = _header_functions()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), "library does not export %s" % n
+    assert sorted(_lib.declared_symbols()) == names, "ctypes signatures out of sync with include/pinn_hip.h"
+
+
+def test_host_only_entry_points(lib):
+    from pinn_amd import _lib, layout
+    assert lib.pinn_abi_version() == 1
+    assert lib.pinn_residuals_workspace_bytes() == 2048 * 32 * 8
+    for H, nh in ((256, 3), (128, 3), (256, 1), (128, 8)):
+        net = _lib.Net(8, H, nh)
+        offs, total = layout.param_offsets(8, H, nh)
+        assert lib.pinn_param_count(ctypes.byref(net)) == total
+        assert lib.pinn_train_workspace_bytes(ctypes.byref(net), 1000) > 0
+    assert layout.param_offsets(8, 256, 3)[1] == 175362 + 6          # 175 362 parameters + two 3-float alignment pads
+    for bad in (_lib.Net(8, 96, 3), _lib.Net(7, 256, 3), _lib.Net(8, 256, 0), _lib.Net(8, 512, 3), _lib.Net(8, 256, 9)):
+        assert lib.pinn_param_count(ctypes.byref(bad)) == -2
+        assert lib.pinn_train_workspace_bytes(ctypes.byref(bad), 1000) == 0
+    # struct layouts agree with the C side (sizes from the header's field lists)
+    assert ctypes.sizeof(_lib.Affine) == 8 * 8 * 2 + 8 * 2 + 4 * 2
+    assert ctypes.sizeof(_lib.Net) == 12
+    assert ctypes.sizeof(_lib.Dropout) == 4 + 36 + 8 + 4 + 4 + 8 + 8   # incl. padding before row_offset
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "physics-informed-neural-network-for-explainable-fault-diagnosis-in-fuel-cells_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pinn_oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_model_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import pinn_amd
+    from pinn_amd import synth
+    ds = synth.make_dataset(64, (), seed=0)
+    with pytest.raises(Exception) as e:
+        pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, 256, 256, 256, 1], ds[4], ds[5], p=0.2, logvar=True)
+    assert "GPU" in str(e.value)
