@@ -22,42 +22,7 @@ struct FwdArgs {
   float* o2;             //                   | MC: e_u
 };
 
-// one forward pass of the whole net for this wave's 32 rows -> (u, z) per lane (both halves hold it)
-template <int H>
-__device__ __forceinline__ void forward_pass(const float* __restrict__ params, const ParamLayout& L, Pipe& pipe,
-                                             const DropDev& d, int mode, const f32x4& xa, const f32x4& xb, int lane,
-                                             long long grow, long long lrow, long long n_rows, unsigned pass, float& u,
-                                             float& z) {
-  constexpr int NB = H / 32, NB2 = H / 64, NB4 = H / 128;
-  const int hh = lane >> 5;
-  f32x16 h[NB];
-  layer_input<NB>(h, params + L.w0(), params + L.b0(), xa, xb, lane);
-  epilogue_tanh_drop<NB>(h, d, mode, 0, hh, grow, lrow, n_rows, pass, nullptr);
-#pragma unroll 1
-  for (int l = 1; l < L.nh; ++l) {
-    f32x16 acc[NB];
-    load_bias<NB>(acc, params + L.b(l), hh);
-    layer_forward<NB, NB>(acc, h, pipe, lane);
-    epilogue_tanh_drop<NB>(acc, d, mode, l, hh, grow, lrow, n_rows, pass, nullptr);
-#pragma unroll
-    for (int mt = 0; mt < NB; ++mt) h[mt] = acc[mt];
-  }
-  u = head_dot<NB>(h, params + L.wp(), hh) + params[L.bp()];
-  f32x16 v1[NB2];
-  load_bias<NB2>(v1, params + L.bv0(), hh);
-  layer_forward<NB, NB2>(v1, h, pipe, lane);
-  epilogue_tanh_drop<NB2>(v1, d, mode, L.nh, hh, grow, lrow, n_rows, pass, nullptr);
-  f32x16 v2[NB4];
-  load_bias<NB4>(v2, params + L.bv1(), hh);
-  layer_forward<NB2, NB4>(v2, v1, pipe, lane);
-#pragma unroll
-  for (int mt = 0; mt < NB4; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v2[mt][r] = tanh_f32(v2[mt][r]);
-  z = head_dot<NB4>(v2, params + L.wv2(), hh) + params[L.bv2()];
-}
-
-template <int H, bool MC>
+template <int H, bool MC, bool kBits>
 __global__ __launch_bounds__(kThreads, 1) void mlp_kernel(FwdArgs a) {
   __shared__ __attribute__((aligned(16))) char lds_w[2 * kChunkBytes];
   __shared__ ChunkDesc tab[kMaxChunks];
@@ -78,9 +43,12 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_kernel(FwdArgs a) {
     const long long grow = a.drop.row_offset + lrow;
     const f32x4 xa = reinterpret_cast<const f32x4*>(a.x)[srow * 2];
     const f32x4 xb = reinterpret_cast<const f32x4*>(a.x)[srow * 2 + 1];
+    RowCtx c{lane, lane >> 5, grow, srow, a.n_rows, 0u, a.drop.mode};
+    const StashPtrs st{};
+    f32x16 v2[H / 128];
     if (!MC) {
       float u, z;
-      forward_pass<H>(a.params, L, pipe, a.drop, a.drop.mode, xa, xb, lane, grow, srow, a.n_rows, 0u, u, z);
+      forward_pass<H, false, kBits>(a.params, L, pipe, a.drop, c, xa, xb, st, u, z, v2);
       if (valid && lane < 32) {
         a.o0[lrow] = u;
         a.o1[lrow] = logf(softplus_f32(z) + 1e-6f);
@@ -90,9 +58,10 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_kernel(FwdArgs a) {
       float u_eval = 0.f, s1 = 0.f, s2 = 0.f, sl = 0.f;
 #pragma unroll 1
       for (int t = -1; t < a.n_passes; ++t) {
-        const int mode = (t < 0) ? PINN_DROP_NONE : a.drop.mode;
+        c.mode = (t < 0) ? PINN_DROP_NONE : a.drop.mode;
+        c.pass = (unsigned)(t < 0 ? 0 : t);
         float u, z;
-        forward_pass<H>(a.params, L, pipe, a.drop, mode, xa, xb, lane, grow, srow, a.n_rows, (unsigned)(t < 0 ? 0 : t), u, z);
+        forward_pass<H, false, kBits>(a.params, L, pipe, a.drop, c, xa, xb, st, u, z, v2);
         if (t < 0) {
           u_eval = u;
         } else {
@@ -167,10 +136,14 @@ static int launch(const pinn_net_t* net, const FwdArgs& a, void* stream) {
   if (n_tiles == 0) return PINN_OK;
   const int grid = (int)(n_tiles < num_cus() ? n_tiles : num_cus());
   (void)hipGetLastError();   // drop a stale error left by another HIP user of this thread
-  if (net->hidden == 256)
-    hipLaunchKernelGGL((mlp_kernel<256, MC>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL((mlp_kernel<128, MC>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
+  const bool bits = a.drop.mode == PINN_DROP_BITS;
+  if (net->hidden == 256) {
+    if (bits) hipLaunchKernelGGL((mlp_kernel<256, MC, true>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((mlp_kernel<256, MC, false>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
+  } else {
+    if (bits) hipLaunchKernelGGL((mlp_kernel<128, MC, true>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((mlp_kernel<128, MC, false>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;
 }

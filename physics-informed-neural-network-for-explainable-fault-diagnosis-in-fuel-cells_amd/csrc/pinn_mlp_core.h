@@ -81,39 +81,37 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
-// 16 keep bits (bit r <-> register r) of feature block `fb` of dropout module `layer`
-// for this lane's row.  `grow` = GLOBAL row index, `lrow` = local row (BITS mode).
-__device__ __forceinline__ unsigned keep_bits(const DropDev& d, int mode, int layer, int fb, int hh, long long grow,
+// 16 keep bits (bit r <-> register r) of feature block `fb` of dropout module `layer` for this
+// lane's row.  Branch-free so it can be scheduled into MFMA shadows: eval mode is thr = 0
+// (every draw kept).  kBits = true (parity-test kernels only) reads injected bit masks instead.
+template <bool kBits>
+__device__ __forceinline__ unsigned keep_bits(const DropDev& d, unsigned thr, int layer, int fb, int hh, long long grow,
                                               long long lrow, long long n_rows, unsigned pass) {
-  if (mode == PINN_DROP_PHILOX) {
-    unsigned keep = 0;
-    const unsigned thr = d.thr[layer];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      unsigned o[4];
-      philox4x32_10((unsigned)grow, (unsigned)((unsigned long long)grow >> 32),
-                    ((unsigned)layer << 16) | ((unsigned)fb << 2) | ((unsigned)hh << 1) | (unsigned)c,
-                    d.stream + pass, d.seed_lo, d.seed_hi, o);
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const unsigned draw = (o[w] >> (16 * s)) & 0xFFFFu;
-          const int r = 4 * (2 * c + (w >> 1)) + 2 * (w & 1) + s;
-          keep |= (draw >= thr ? 1u : 0u) << r;
-        }
-      }
-    }
-    return keep;
-  }
-  if (mode == PINN_DROP_BITS) {
+  if (kBits) {
     const unsigned word = d.bits[((long long)pass * n_rows + lrow) * d.words + layer * d.nb + fb];
     unsigned keep = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) keep |= ((word >> (8 * (r >> 2) + 4 * hh + (r & 3))) & 1u) << r;
-    return keep;
+    return thr == 0 ? 0xFFFFu : keep;
   }
-  return 0xFFFFu;
+  unsigned keep = 0;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    unsigned o[4];
+    philox4x32_10((unsigned)grow, (unsigned)((unsigned long long)grow >> 32),
+                  ((unsigned)layer << 16) | ((unsigned)fb << 2) | ((unsigned)hh << 1) | (unsigned)c, d.stream + pass,
+                  d.seed_lo, d.seed_hi, o);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const unsigned draw = (o[w] >> (16 * s)) & 0xFFFFu;
+        const int r = 4 * (2 * c + (w >> 1)) + 2 * (w & 1) + s;
+        keep |= (draw >= thr ? 1u : 0u) << r;
+      }
+    }
+  }
+  return keep;
 }
 
 // tanh in float32: odd polynomial below 1/8 (abs err < 2e-10), 1 - 2/(e^{2x}+1) above
@@ -228,51 +226,74 @@ __device__ __forceinline__ int build_backward_chunks(ChunkDesc* tab, const Param
 // ---------------------------------------------------------------------------------------
 #define PINN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// bias[fb*32 + 8q + 4hh + j] -> accumulator layout
-template <int NBOUT>
-__device__ __forceinline__ void load_bias(f32x16 (&acc)[NBOUT], const float* __restrict__ bias, int hh) {
+template <int NBLK>
+__device__ __forceinline__ void zero_blocks(f32x16 (&v)[NBLK]) {
 #pragma unroll
-  for (int mt = 0; mt < NBOUT; ++mt) {
+  for (int mt = 0; mt < NBLK; ++mt)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(bias + mt * 32 + 8 * q + 4 * hh);
-      acc[mt][4 * q + 0] = b[0]; acc[mt][4 * q + 1] = b[1]; acc[mt][4 * q + 2] = b[2]; acc[mt][4 * q + 3] = b[3];
-    }
-  }
+    for (int r = 0; r < 16; ++r) v[mt][r] = 0.0f;
 }
 
-// out^T[f2][n] += sum_f W[f2][f] h^T[f][n] over the NBIN input blocks; one forward slab per block
-template <int NBIN, int NBOUT>
-__device__ __forceinline__ void layer_forward(f32x16 (&acc)[NBOUT], const f32x16 (&h)[NBIN], Pipe& pipe, int lane) {
+// Per-row context of a lane
+struct RowCtx {
+  int lane, hh;
+  long long grow;     // global row index (Philox counter)
+  long long lrow;     // local row index (injected bit masks)
+  long long n_rows;
+  unsigned pass;
+  int mode;           // PINN_DROP_*
+};
+
+// Forward layer with LAZY input activation.
+//   out^T[f2][n] += sum_f W[f2][f] h^T[f][n], one forward slab per 32-feature input block kb.
+// `prep(kb)` must turn block kb of h from "raw accumulator of the previous layer" into the final
+// activation (bias + tanh + dropout, stash, head partial sums ...).  It is called ONE SLAB AHEAD
+// of its use, in the same scheduling region as the 128 MFMAs of slab kb-1, so its VALU / memory
+// work fills the shadow of those MFMAs instead of idling the matrix pipe between layers.
+template <int NBIN, int NBOUT, typename F>
+__device__ __forceinline__ void layer_forward_lazy(f32x16 (&acc)[NBOUT], const f32x16 (&h)[NBIN], Pipe& pipe, int lane,
+                                                   F&& prep) {
   const int hh = lane >> 5, i = lane & 31;
   const int sw = (i >> 1) & 7;
   const int base = i * 128;
+  prep(0);
 #pragma unroll
   for (int kb = 0; kb < NBIN; ++kb) {
+    if (kb + 1 < NBIN) prep(kb + 1);
     const char* buf = pipe.cur() + base;
+    // A fragments (16 B = four k-steps of one 32x32 output tile) are fetched kAhead groups before use
+    constexpr int kGroups = 4 * NBOUT, kAhead = 2;
+    f32x4 afrag[kAhead + 1];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int off = ((2 * g + hh) ^ sw) << 4;
+    for (int p = 0; p < kAhead; ++p)
+      afrag[p] = *reinterpret_cast<const f32x4*>(buf + (((2 * (p / NBOUT) + hh) ^ sw) << 4) + (p % NBOUT) * 4096);
 #pragma unroll
-      for (int mt = 0; mt < NBOUT; ++mt) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(buf + off + mt * 4096);
-        acc[mt] = PINN_MFMA(a[0], h[kb][4 * g + 0], acc[mt]);
-        acc[mt] = PINN_MFMA(a[1], h[kb][4 * g + 1], acc[mt]);
-        acc[mt] = PINN_MFMA(a[2], h[kb][4 * g + 2], acc[mt]);
-        acc[mt] = PINN_MFMA(a[3], h[kb][4 * g + 3], acc[mt]);
+    for (int gi = 0; gi < kGroups; ++gi) {
+      const int g = gi / NBOUT, mt = gi % NBOUT;
+      if (gi + kAhead < kGroups) {
+        const int gn = (gi + kAhead) / NBOUT, mn = (gi + kAhead) % NBOUT;
+        afrag[(gi + kAhead) % (kAhead + 1)] = *reinterpret_cast<const f32x4*>(buf + (((2 * gn + hh) ^ sw) << 4) + mn * 4096);
       }
+      const f32x4 a = afrag[gi % (kAhead + 1)];
+      acc[mt] = PINN_MFMA(a[0], h[kb][4 * g + 0], acc[mt]);
+      acc[mt] = PINN_MFMA(a[1], h[kb][4 * g + 1], acc[mt]);
+      acc[mt] = PINN_MFMA(a[2], h[kb][4 * g + 2], acc[mt]);
+      acc[mt] = PINN_MFMA(a[3], h[kb][4 * g + 3], acc[mt]);
     }
     pipe.advance();
   }
 }
 
-// din^T[f][n] += sum_f2 W[f2][f] dpre^T[f2][n]; one backward slab (32 rows of W) per dpre block
-template <int NBK, int NBOUT>
-__device__ __forceinline__ void layer_backward(f32x16 (&acc)[NBOUT], const f32x16 (&dpre)[NBK], Pipe& pipe, int lane,
-                                               int ld) {
+// Backward (dgrad) layer with lazy operand preparation:
+//   din^T[f][n] += sum_f2 W[f2][f] dpre^T[f2][n]; one backward slab (32 rows of W) per dpre block.
+template <int NBK, int NBOUT, typename F>
+__device__ __forceinline__ void layer_backward_lazy(f32x16 (&acc)[NBOUT], const f32x16 (&dpre)[NBK], Pipe& pipe, int lane,
+                                                    int ld, F&& prep) {
   const int hh = lane >> 5, i = lane & 31;
+  prep(0);
 #pragma unroll
   for (int kb = 0; kb < NBK; ++kb) {
+    if (kb + 1 < NBK) prep(kb + 1);
     const float* buf = reinterpret_cast<const float*>(pipe.cur()) + i;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -289,63 +310,159 @@ __device__ __forceinline__ void layer_backward(f32x16 (&acc)[NBOUT], const f32x1
   }
 }
 
-// input layer: acc = b0 + W0 x^T, W0 [H, 8] read straight from global (8 KB, cache resident)
+// input layer: acc = W0 x^T (bias added by the lazy activation), W0 [H, 8] read straight from global
 template <int NBOUT>
-__device__ __forceinline__ void layer_input(f32x16 (&acc)[NBOUT], const float* __restrict__ W0,
-                                            const float* __restrict__ b0, const f32x4& xa, const f32x4& xb, int lane) {
+__device__ __forceinline__ void layer_input(f32x16 (&acc)[NBOUT], const float* __restrict__ W0, const f32x4& xa,
+                                            const f32x4& xb, int lane) {
   const int hh = lane >> 5, i = lane & 31;
-  load_bias<NBOUT>(acc, b0, hh);
   const float x0 = hh ? xa[1] : xa[0], x1 = hh ? xa[3] : xa[2], x2 = hh ? xb[1] : xb[0], x3 = hh ? xb[3] : xb[2];
 #pragma unroll
   for (int mt = 0; mt < NBOUT; ++mt) {
     const f32x4 wa = *reinterpret_cast<const f32x4*>(W0 + (mt * 32 + i) * 8);
     const f32x4 wb = *reinterpret_cast<const f32x4*>(W0 + (mt * 32 + i) * 8 + 4);
-    acc[mt] = PINN_MFMA(hh ? wa[1] : wa[0], x0, acc[mt]);
-    acc[mt] = PINN_MFMA(hh ? wa[3] : wa[2], x1, acc[mt]);
-    acc[mt] = PINN_MFMA(hh ? wb[1] : wb[0], x2, acc[mt]);
-    acc[mt] = PINN_MFMA(hh ? wb[3] : wb[2], x3, acc[mt]);
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+    c = PINN_MFMA(hh ? wa[1] : wa[0], x0, c);
+    c = PINN_MFMA(hh ? wa[3] : wa[2], x1, c);
+    c = PINN_MFMA(hh ? wb[1] : wb[0], x2, c);
+    c = PINN_MFMA(hh ? wb[3] : wb[2], x3, c);
+    acc[mt] = c;
   }
 }
 
-// h = dropout(tanh(acc)); returns keep bits through `keep_out` when asked
-template <int NBOUT>
-__device__ __forceinline__ void epilogue_tanh_drop(f32x16 (&acc)[NBOUT], const DropDev& d, int mode, int layer, int hh,
-                                                   long long grow, long long lrow, long long n_rows, unsigned pass,
-                                                   unsigned* keep_out) {
-  const bool drop = mode != PINN_DROP_NONE;
+// one 32-feature block: v = dropout(tanh(v + bias)); returns the 16 keep bits.  Branch-free.
+template <bool kBits>
+__device__ __forceinline__ unsigned activate_block(f32x16& v, const float* __restrict__ bias32, const DropDev& d,
+                                                   const RowCtx& c, int layer, int fb, bool has_drop) {
+  const bool drop = has_drop && c.mode != PINN_DROP_NONE;
+  const unsigned thr = drop ? d.thr[layer] : 0u;
   const float scale = drop ? d.scale[layer] : 1.0f;
+  const unsigned keep = keep_bits<kBits>(d, thr, layer, fb, c.hh, c.grow, c.lrow, c.n_rows, c.pass);
 #pragma unroll
-  for (int mt = 0; mt < NBOUT; ++mt) {
-    unsigned keep = 0xFFFFu;
-    if (drop) keep = keep_bits(d, mode, layer, mt, hh, grow, lrow, n_rows, pass);
-    if (keep_out) keep_out[mt] = keep;
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias32 + 8 * q + 4 * c.hh);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float a = tanh_f32(acc[mt][r]);
-      acc[mt][r] = ((keep >> r) & 1u) ? a * scale : 0.0f;
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * q + j;
+      const float a = tanh_f32(v[r] + b[j]);
+      v[r] = ((keep >> r) & 1u) ? a * scale : 0.0f;
     }
+  }
+  return keep;
+}
+
+// tanh only (no dropout module after this layer)
+__device__ __forceinline__ void activate_block_tanh(f32x16& v, const float* __restrict__ bias32, int hh) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias32 + 8 * q + 4 * hh);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[4 * q + j] = tanh_f32(v[4 * q + j] + b[j]);
   }
 }
 
-// <w, h> over this lane's features, completed across the two lane halves
-template <int NBIN>
-__device__ __forceinline__ float head_dot(const f32x16 (&h)[NBIN], const float* __restrict__ w, int hh) {
-  float s = 0.0f;
+// partial <w, h> over one block (this lane's 16 features)
+__device__ __forceinline__ float block_dot(const f32x16& h, const float* __restrict__ w32, int hh, float s) {
 #pragma unroll
-  for (int fb = 0; fb < NBIN; ++fb) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + fb * 32 + 8 * q + 4 * hh);
-      s = fmaf(wv[0], h[fb][4 * q + 0], s);
-      s = fmaf(wv[1], h[fb][4 * q + 1], s);
-      s = fmaf(wv[2], h[fb][4 * q + 2], s);
-      s = fmaf(wv[3], h[fb][4 * q + 3], s);
-    }
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(w32 + 8 * q + 4 * hh);
+    s = fmaf(wv[0], h[4 * q + 0], s);
+    s = fmaf(wv[1], h[4 * q + 1], s);
+    s = fmaf(wv[2], h[4 * q + 2], s);
+    s = fmaf(wv[3], h[4 * q + 3], s);
   }
-  return s + __shfl_xor(s, 32, 64);
+  return s;
+}
+
+// element (feature f, row n) of 32-row tile `tile32` of an F-feature tensor lives at ((tile32*F + f)*32 + n):
+// one block = 16 dword accesses per lane, each wave-instruction two contiguous 128-B segments
+__device__ __forceinline__ float* tiled_block_ptr(float* base, long long tile32, int F, int fb, int lane) {
+  return base + (tile32 * F + fb * 32 + 4 * (lane >> 5)) * 32 + (lane & 31);
+}
+__device__ __forceinline__ void store_block(float* __restrict__ p, const f32x16& v) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * 32] = v[r];
+}
+__device__ __forceinline__ void load_block(const float* __restrict__ p, f32x16& v) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = p[((r & 3) + 8 * (r >> 2)) * 32];
 }
 
 // logvar = log(softplus(z) + 1e-6), softplus with torch's threshold 20 (01:432-434)
 __device__ __forceinline__ float softplus_f32(float z) { return z > 20.0f ? z : log1pf(expf(z)); }
+
+// ---------------------------------------------------------------------------------------
+// One forward pass of the whole net for this wave's 32 rows -> (u, z); both lane halves hold them.
+// TRAIN: also parks the keep bits in LDS (keep[(module*NB + block)*64]) and writes the
+// post-dropout activations to the tiled stash.
+// ---------------------------------------------------------------------------------------
+struct StashPtrs {
+  float* h;        // [nh][T32][H][32]
+  float* v1;       // [T32][H/2][32]
+  float* v2;       // [T32][H/4][32]
+  long long t32_total;
+  long long tile32;
+  unsigned short* keep;   // this lane's LDS slot base
+};
+
+template <int H, bool TRAIN, bool kBits>
+__device__ __forceinline__ void forward_pass(const float* __restrict__ P, const ParamLayout& L, Pipe& pipe, const DropDev& d,
+                                             const RowCtx& c, const f32x4& xa, const f32x4& xb, const StashPtrs& st, float& u,
+                                             float& z, f32x16 (&v2)[H / 128]) {
+  constexpr int NB = H / 32, NB2 = H / 64, NB4 = H / 128;
+  const int lane = c.lane, hh = c.hh;
+  f32x16 h[NB];
+  layer_input<NB>(h, P + L.w0(), xa, xb, lane);
+  // hidden layers 1 .. nh-1: while layer l's slabs multiply, layer l-1's raw output is activated block by block
+#pragma unroll 1
+  for (int l = 1; l < L.nh; ++l) {
+    f32x16 acc[NB];
+    zero_blocks<NB>(acc);
+    const float* bias = P + (l == 1 ? L.b0() : L.b(l - 1));
+    layer_forward_lazy<NB, NB>(acc, h, pipe, lane, [&](int kb) {
+      const unsigned keep = activate_block<kBits>(h[kb], bias + kb * 32, d, c, l - 1, kb, true);
+      if (TRAIN) {
+        st.keep[((l - 1) * NB + kb) * 64] = (unsigned short)keep;
+        store_block(tiled_block_ptr(st.h + (long long)(l - 1) * st.t32_total * H * 32, st.tile32, H, kb, lane), h[kb]);
+      }
+    });
+#pragma unroll
+    for (int mt = 0; mt < NB; ++mt) h[mt] = acc[mt];
+  }
+  // h = raw output of the last hidden layer; its activation + the predict head ride on the variance head's first layer
+  f32x16 v1[NB2];
+  zero_blocks<NB2>(v1);
+  float up = 0.0f;
+  {
+    const int ll = L.nh - 1;
+    const float* bias = P + (ll == 0 ? L.b0() : L.b(ll));
+    layer_forward_lazy<NB, NB2>(v1, h, pipe, lane, [&](int kb) {
+      const unsigned keep = activate_block<kBits>(h[kb], bias + kb * 32, d, c, ll, kb, true);
+      up = block_dot(h[kb], P + L.wp() + kb * 32, hh, up);
+      if (TRAIN) {
+        st.keep[(ll * NB + kb) * 64] = (unsigned short)keep;
+        store_block(tiled_block_ptr(st.h + (long long)ll * st.t32_total * H * 32, st.tile32, H, kb, lane), h[kb]);
+      }
+    });
+  }
+  u = up + __shfl_xor(up, 32, 64) + P[L.bp()];
+  zero_blocks<NB4>(v2);
+  layer_forward_lazy<NB2, NB4>(v2, v1, pipe, lane, [&](int kb) {
+    const unsigned keep = activate_block<kBits>(v1[kb], P + L.bv0() + kb * 32, d, c, L.nh, kb, true);
+    if (TRAIN) {
+      st.keep[(L.nh * NB + kb) * 64] = (unsigned short)keep;
+      store_block(tiled_block_ptr(st.v1, st.tile32, H / 2, kb, lane), v1[kb]);
+    }
+  });
+  float zp = 0.0f;
+#pragma unroll
+  for (int mt = 0; mt < NB4; ++mt) {
+    activate_block_tanh(v2[mt], P + L.bv1() + mt * 32, hh);
+    zp = block_dot(v2[mt], P + L.wv2() + mt * 32, hh, zp);
+    if (TRAIN) store_block(tiled_block_ptr(st.v2, st.tile32, H / 4, mt, lane), v2[mt]);
+  }
+  z = zp + __shfl_xor(zp, 32, 64) + P[L.bv2()];
+}
 
 }  // namespace pinn
