@@ -63,19 +63,20 @@ def philox_keep_mask(seed, stream, row0, n_rows, layer_id, width, p):
     One Philox call yields eight 16-bit draws.  For feature f of dropout layer `layer_id`
     (0-based over the net's Dropout modules) and GLOBAL row index g = row0 + r:
         counter = (g & 0xffffffff, g >> 32, layer_id << 16 | call, stream),  key = (seed lo, hi)
-        call = (f >> 5) << 2 | ((f >> 2) & 1) << 1 | ((f >> 4) & 1)
-        word = 2 * ((f >> 3) & 1) + ((f >> 1) & 1),   half = f & 1  (0 = low 16 bits)
-    so a mask depends only on (seed, stream, global row, layer, feature): it is invariant
-    under any row -> GPU / workgroup / lane assignment (SURVEY.md §8(e), §9.4).
+        call = (f >> 5) << 2 | ((f >> 2) & 3)
+        idx  = 4 * ((f >> 4) & 1) + (f & 3);  word = idx >> 1,  half = idx & 1  (0 = low 16 bits)
+    (the eight features {32p + 16b + 4q + r : b in 0..1, r in 0..3} that one MFMA lane holds share
+    one call), so a mask depends only on (seed, stream, global row, layer, feature): it is invariant
+    under any row -> GPU / workgroup / lane assignment (SURVEY.md 8(e), 9.4).
     `stream` is the optimizer step (training) or the pass index (MC-dropout).
     """
     thr = dropout_threshold16(p)
     g = (np.arange(n_rows, dtype=np.uint64) + np.uint64(row0))[:, None]
     f = np.arange(width, dtype=np.uint64)[None, :]
-    call = ((f >> np.uint64(5)) << np.uint64(2)) | (((f >> np.uint64(2)) & np.uint64(1)) << np.uint64(1)) \
-        | ((f >> np.uint64(4)) & np.uint64(1))
-    word = (np.uint64(2) * ((f >> np.uint64(3)) & np.uint64(1)) + ((f >> np.uint64(1)) & np.uint64(1))).astype(np.int64)
-    half = (f & np.uint64(1)).astype(np.int64)
+    call = ((f >> np.uint64(5)) << np.uint64(2)) | ((f >> np.uint64(2)) & np.uint64(3))
+    idx = (np.uint64(4) * ((f >> np.uint64(4)) & np.uint64(1)) + (f & np.uint64(3))).astype(np.int64)
+    word = idx >> 1
+    half = idx & 1
     c2 = (np.uint64(layer_id) << np.uint64(16)) | call
     out = philox4x32_10(g & _MASK32, g >> np.uint64(32), c2, np.uint64(int(stream) & 0xFFFFFFFF),
                         int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)

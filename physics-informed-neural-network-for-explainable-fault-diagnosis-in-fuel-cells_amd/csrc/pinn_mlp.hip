@@ -5,7 +5,8 @@
 //                         launch; running sums of u, u^2, logvar stay in registers, masks come
 //                         from on-chip Philox keyed by (seed, pass, global row, layer, feature);
 //                         HBM traffic is 32 B in + 12 B out per row regardless of T.
-// Both are MFMA-bound (v_mfma_f32_32x32x2_f32, exact fp32); see pinn_mlp_core.h for the layout.
+// Both are MFMA-bound (v_mfma_f32_16x16x4_f32, exact fp32); see pinn_mlp_core.h for the layout.
+// 64-row workgroup tiles, two workgroups per CU (persistent grid = 2 x #CU).
 #include "pinn_mlp_core.h"
 
 namespace pinn {
@@ -23,7 +24,7 @@ struct FwdArgs {
 };
 
 template <int H, bool MC, bool kBits>
-__global__ __launch_bounds__(kThreads, 1) void mlp_kernel(FwdArgs a) {
+__global__ __launch_bounds__(kThreads, 2) void mlp_kernel(FwdArgs a) {
   __shared__ __attribute__((aligned(16))) char lds_w[2 * kChunkBytes];
   __shared__ ChunkDesc tab[kMaxChunks];
   ParamLayout L{a.H, a.nh};
@@ -37,19 +38,19 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_kernel(FwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const long long lrow = tile * kTileRows + wave * kWaveRows + (lane & 31);
+    const long long lrow = tile * kTileRows + wave * kWaveRows + (lane & 15);
     const bool valid = lrow < a.n_rows;
     const long long srow = valid ? lrow : a.n_rows - 1;
     const long long grow = a.drop.row_offset + lrow;
     const f32x4 xa = reinterpret_cast<const f32x4*>(a.x)[srow * 2];
     const f32x4 xb = reinterpret_cast<const f32x4*>(a.x)[srow * 2 + 1];
-    RowCtx c{lane, lane >> 5, grow, srow, a.n_rows, 0u, a.drop.mode};
+    RowCtx c{lane, lane >> 4, grow, srow, a.n_rows, 0u, a.drop.mode};
     const StashPtrs st{};
-    f32x16 v2[H / 128];
+    f32x4 v2[H / 64];
     if (!MC) {
       float u, z;
       forward_pass<H, false, kBits>(a.params, L, pipe, a.drop, c, xa, xb, st, u, z, v2);
-      if (valid && lane < 32) {
+      if (valid && lane < 16) {
         a.o0[lrow] = u;
         a.o1[lrow] = logf(softplus_f32(z) + 1e-6f);
       }
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_kernel(FwdArgs a) {
           sl += logf(softplus_f32(z) + 1e-6f);
         }
       }
-      if (valid && lane < 32) {
+      if (valid && lane < 16) {
         const float inv_t = 1.0f / (float)a.n_passes;
         const float m = s1 * inv_t;
         const float var = fmaxf(s2 * inv_t - m * m, 0.0f);
@@ -134,7 +135,7 @@ template <bool MC>
 static int launch(const pinn_net_t* net, const FwdArgs& a, void* stream) {
   const long long n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
   if (n_tiles == 0) return PINN_OK;
-  const int grid = (int)(n_tiles < num_cus() ? n_tiles : num_cus());
+  const int grid = (int)(n_tiles < 2 * num_cus() ? n_tiles : 2 * num_cus());
   (void)hipGetLastError();   // drop a stale error left by another HIP user of this thread
   const bool bits = a.drop.mode == PINN_DROP_BITS;
   if (net->hidden == 256) {

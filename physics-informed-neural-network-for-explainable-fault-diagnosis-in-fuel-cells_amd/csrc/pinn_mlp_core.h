@@ -1,19 +1,25 @@
 // pinn_mlp_core.h -- device-side building blocks of the fused MLP chain for gfx950.
 //
-// Layout ("feature-major chain"): one wave owns 32 rows of the time series.  Every
+// Layout ("feature-major chain"): one wave owns 16 rows of the time series.  Every
 // activation tensor of the net lives in that wave's registers TRANSPOSED, as blocks of
-// 32 features x 32 rows in the C/D layout of v_mfma_f32_32x32x2_f32:
-//     lane l = (hh = l >> 5, n = l & 31) holds, in register r of block fb,
-//     feature fb*32 + (r & 3) + 8*(r >> 2) + 4*hh   of row n.
+// 16 features x 16 rows in the C/D layout of v_mfma_f32_16x16x4_f32:
+//     lane l = (kq = l >> 4, n = l & 15) holds, in register r of block ib,
+//     feature ib*16 + 4*kq + r   of row n.
 // With that layout the accumulator of layer l is, register for register, the B operand of
-// layer l+1 (k-pair of MFMA step r = features {.., ..+4}), so the whole chain
-//     x -> tanh(W0 x) -> ... -> heads
-// runs without moving an activation through LDS or HBM.  Only weights stream: each
-// H x 32 (forward) or 32 x H (backward) slab of a torch-layout [out, in] matrix is staged
-// global -> registers -> LDS once per workgroup (4 waves = 128 rows share it) in a
-// two-buffer pipeline, and read back as MFMA A fragments.
+// layer l+1 (MFMA k-step r of input block ib contracts features {r, 4+r, 8+r, 12+r} of the
+// block), so the whole chain  x -> tanh(W0 x) -> ... -> heads  runs without moving an
+// activation through LDS or HBM.  Only weights stream: each [out x 32] (forward) or [32 x in]
+// (backward) slab of a torch-layout [out, in] matrix is staged global -> registers -> LDS once
+// per workgroup (4 waves = 64 rows share it) in a two-buffer pipeline, and read back as MFMA A
+// fragments (forward: one conflict-free ds_read_b128 = four k-steps).
 //
-// Exact fp32: v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain (no reduced precision), so
+// Occupancy is part of the design: 64 + 64 activation/accumulator registers keep a wave under
+// 256 registers, so TWO independent workgroups share a CU (2 waves per SIMD).  Their barriers,
+// activation (tanh / Philox) phases and weight staging are uncorrelated, so one workgroup's
+// VALU and wait time hides under the other's MFMAs -- hipcc will not interleave the two inside
+// a single wave (checked in the ISA), the hardware does it across waves.
+//
+// Exact fp32: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (no reduced precision), so
 // results agree with the reference's float32 CPU path to summation-order noise.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -22,12 +28,11 @@
 
 namespace pinn {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kThreads = 256;        // 4 waves, one per SIMD (the chain needs > 256 registers/lane)
-constexpr int kWaveRows = 32;
-constexpr int kTileRows = 128;       // rows per workgroup tile
+constexpr int kThreads = 256;        // 4 waves; two such workgroups per CU
+constexpr int kWaveRows = 16;
+constexpr int kTileRows = 64;        // rows per workgroup tile
 constexpr int kChunkBytes = 32768;   // one weight slab in LDS
 constexpr int kMaxChunks = 160;
 constexpr int kMaxDrop = 9;
@@ -40,7 +45,7 @@ struct ParamLayout {
   __host__ __device__ long long w0() const { return 0; }
   __host__ __device__ long long b0() const { return 8LL * H; }
   __host__ __device__ long long w(int l) const { return 9LL * H + (long long)(l - 1) * ((long long)H * H + H); }  // l >= 1
-  __host__ __device__ long long b(int l) const { return w(l) + (long long)H * H; }
+  __host__ __device__ long long b(int l) const { return l == 0 ? b0() : w(l) + (long long)H * H; }
   __host__ __device__ long long wp() const { return 9LL * H + (long long)(nh - 1) * ((long long)H * H + H); }
   __host__ __device__ long long bp() const { return wp() + H; }
   __host__ __device__ long long wv0() const { return bp() + 4; }   // every tensor starts 16-B aligned
@@ -81,59 +86,59 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
-// 16 keep bits (bit r <-> register r) of feature block `fb` of dropout module `layer` for this
-// lane's row.  Branch-free so it can be scheduled into MFMA shadows: eval mode is thr = 0
-// (every draw kept).  kBits = true (parity-test kernels only) reads injected bit masks instead.
+// Per-row context of a lane
+struct RowCtx {
+  int lane, kq;
+  long long grow;     // global row index (Philox counter)
+  long long lrow;     // local row index (injected bit masks)
+  long long n_rows;
+  unsigned pass;
+  int mode;           // PINN_DROP_*
+};
+
+// 8 keep bits of the 32-feature group `fp` (= two 16-feature blocks 2fp, 2fp+1) of dropout
+// module `layer` for this lane's row: bit 4*b + r <-> register r of block 2fp + b, i.e. feature
+// 32fp + 16b + 4kq + r.  ONE Philox call = eight 16-bit draws = exactly this lane's share:
+//     counter = (global_row lo, hi, layer << 16 | fp << 2 | kq, stream + pass), key = seed
+//     draw index 4b + r -> word (4b + r) >> 1, half (4b + r) & 1.
+// Branch-free: eval mode is thr = 0 (every draw kept).  kBits (parity-test kernels only) reads
+// injected bit masks instead.
 template <bool kBits>
-__device__ __forceinline__ unsigned keep_bits(const DropDev& d, unsigned thr, int layer, int fb, int hh, long long grow,
-                                              long long lrow, long long n_rows, unsigned pass) {
+__device__ __forceinline__ unsigned keep_bits8(const DropDev& d, const RowCtx& c, unsigned thr, int layer, int fp) {
   if (kBits) {
-    const unsigned word = d.bits[((long long)pass * n_rows + lrow) * d.words + layer * d.nb + fb];
-    unsigned keep = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) keep |= ((word >> (8 * (r >> 2) + 4 * hh + (r & 3))) & 1u) << r;
-    return thr == 0 ? 0xFFFFu : keep;
+    const unsigned word = d.bits[((long long)c.pass * c.n_rows + c.lrow) * d.words + layer * d.nb + fp];
+    const unsigned lo = (word >> (4 * c.kq)) & 0xFu, hi = (word >> (16 + 4 * c.kq)) & 0xFu;
+    return thr == 0 ? 0xFFu : (lo | (hi << 4));
   }
+  unsigned o[4];
+  philox4x32_10((unsigned)c.grow, (unsigned)((unsigned long long)c.grow >> 32),
+                ((unsigned)layer << 16) | ((unsigned)fp << 2) | (unsigned)c.kq, d.stream + c.pass, d.seed_lo, d.seed_hi, o);
   unsigned keep = 0;
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    unsigned o[4];
-    philox4x32_10((unsigned)grow, (unsigned)((unsigned long long)grow >> 32),
-                  ((unsigned)layer << 16) | ((unsigned)fb << 2) | ((unsigned)hh << 1) | (unsigned)c, d.stream + pass,
-                  d.seed_lo, d.seed_hi, o);
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const unsigned draw = (o[w] >> (16 * s)) & 0xFFFFu;
-        const int r = 4 * (2 * c + (w >> 1)) + 2 * (w & 1) + s;
-        keep |= (draw >= thr ? 1u : 0u) << r;
-      }
-    }
+  for (int w = 0; w < 4; ++w) {
+    keep |= ((o[w] & 0xFFFFu) >= thr ? 1u : 0u) << (2 * w);
+    keep |= ((o[w] >> 16) >= thr ? 1u : 0u) << (2 * w + 1);
   }
   return keep;
 }
 
-// tanh in float32: odd polynomial below 1/8 (abs err < 2e-10), 1 - 2/(e^{2x}+1) above
-// (v_exp_f32 + v_rcp_f32; abs err ~1e-7).
+// tanh(x) = 1 - 2 / (e^{2x} + 1): v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma -- five VALU issues.
+// f32 MFMA and f32 VALU share one datapath on gfx950 (tools/mfma_valu_share.hip: concurrent streams
+// take the SUM of their times), so every VALU cycle here is a lost MFMA cycle: keep it minimal.
+// Absolute error ~1.5e-7 (exp2 / rcp are 1-ulp approximations); saturates correctly at +-1.
 __device__ __forceinline__ float tanh_f32(float x) {
-  const float ax = fabsf(x);
-  const float x2 = x * x;
-  const float poly = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f))));
-  const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);   // e^{2|x|}
-  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-  const float big = copysignf(t, x);
-  return ax < 0.125f ? poly : big;
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // e^{2x}
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
 // ---------------------------------------------------------------------------------------
 // weight-slab pipeline: global -> registers -> LDS, two buffers, one barrier per slab
 // ---------------------------------------------------------------------------------------
 struct ChunkDesc {
-  unsigned off;      // float offset of the slab's first element in the flat parameter buffer
-  unsigned short ld; // row stride (floats) of the source matrix
+  unsigned off;         // float offset of the slab's first element in the flat parameter buffer
+  unsigned short ld;    // row stride (floats) of the source matrix
   unsigned char kind;   // 0: forward slab  [rows][32 cols], 16-B chunks XOR-swizzled by (row>>1)&7
-                        // 1: backward slab [32 rows][ld cols], contiguous copy
+                        // 1: backward slab [32 rows][ld cols], column bit 4 XOR-ed with bit 2 of the row
   unsigned char np;     // 16-byte pieces per thread (slab bytes / 4096)
 };
 
@@ -145,6 +150,9 @@ struct Pipe {
   f32x4 regs[8];
   ChunkDesc pending;
 
+  // Branch-free on purpose: with `if (p < np)` around each load hipcc emits s_waitcnt vmcnt(0) before
+  // every conditional global_load and the eight slab loads serialise (8 x L2 latency per slab).
+  // Slabs smaller than 32 KB simply re-load / re-store their last piece (same address, same data).
   __device__ __forceinline__ void issue(int idx) {
     pending = tab[idx];
     const int tid = threadIdx.x;
@@ -157,20 +165,27 @@ struct Pipe {
       g = params + pending.off + tid * 4;
       gstride = 1024;
     }
+    const int last = pending.np - 1;
 #pragma unroll
-    for (int p = 0; p < 8; ++p)
-      if (p < pending.np) regs[p] = *reinterpret_cast<const f32x4*>(g + p * gstride);
+    for (int p = 0; p < 8; ++p) regs[p] = *reinterpret_cast<const f32x4*>(g + (p < last ? p : last) * gstride);
   }
   __device__ __forceinline__ void commit(int buf) {
     const int tid = threadIdx.x;
     char* dst = lds + buf * kChunkBytes;
-    if (pending.kind == 0)
-      dst += (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
-    else
-      dst += tid * 16;
+    const int last = pending.np - 1;
+    // forward slab: row = 32 p + tid/8, 16-B chunk (tid & 7) XOR-swizzled by (row >> 1) & 7.
+    // backward slab: piece idx = p*256 + tid covers floats [4 idx, 4 idx + 4), row = 4 idx / ld; rows with
+    // bit 2 set (kq odd in the reader) get column bit 4 flipped -> conflict-free ds_read_b32.
+    const int fwd_off = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
+    const int sh = 31 - __clz((int)pending.ld) - 2;        // log2(ld / 4)
+    const bool fwd = pending.kind == 0;
 #pragma unroll
-    for (int p = 0; p < 8; ++p)
-      if (p < pending.np) *reinterpret_cast<f32x4*>(dst + p * 4096) = regs[p];
+    for (int p = 0; p < 8; ++p) {
+      const int pp = p < last ? p : last;
+      const int idx = pp * 256 + tid;
+      const int bwd_off = (idx * 16) ^ ((((idx >> sh) >> 2) & 1) << 6);
+      *reinterpret_cast<f32x4*>(dst + (fwd ? fwd_off + pp * 4096 : bwd_off)) = regs[p];
+    }
   }
   // stage slab 0 synchronously, then start fetching slab 1
   __device__ __forceinline__ void prime() {
@@ -186,9 +201,8 @@ struct Pipe {
     commit((ci + 1) & 1);
     __syncthreads();
     ++ci;
-    int nxt = ci + 1;
     // the slab index cycles with period n; ci itself keeps counting so buffer parity alternates
-    issue(nxt % n);
+    issue((ci + 1) % n);
   }
 };
 
@@ -222,247 +236,238 @@ __device__ __forceinline__ int build_backward_chunks(ChunkDesc* tab, const Param
 }
 
 // ---------------------------------------------------------------------------------------
-// MFMA layer bodies
+// MFMA layer bodies (block = 16 features x 16 rows = one f32x4 per lane)
 // ---------------------------------------------------------------------------------------
-#define PINN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define PINN_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-template <int NBLK>
-__device__ __forceinline__ void zero_blocks(f32x16 (&v)[NBLK]) {
+template <int NT>
+__device__ __forceinline__ void zero_blocks(f32x4 (&v)[NT]) {
 #pragma unroll
-  for (int mt = 0; mt < NBLK; ++mt)
+  for (int t = 0; t < NT; ++t) v[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+// accumulators start at the layer's bias (costs the same as zeroing them, saves an add per element later)
+template <int NT>
+__device__ __forceinline__ void bias_blocks(f32x4 (&v)[NT], const float* __restrict__ bias, int kq) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[mt][r] = 0.0f;
+  for (int t = 0; t < NT; ++t) v[t] = *reinterpret_cast<const f32x4*>(bias + t * 16 + 4 * kq);
 }
 
-// Per-row context of a lane
-struct RowCtx {
-  int lane, hh;
-  long long grow;     // global row index (Philox counter)
-  long long lrow;     // local row index (injected bit masks)
-  long long n_rows;
-  unsigned pass;
-  int mode;           // PINN_DROP_*
-};
-
-// Forward layer with LAZY input activation.
-//   out^T[f2][n] += sum_f W[f2][f] h^T[f][n], one forward slab per 32-feature input block kb.
-// `prep(kb)` must turn block kb of h from "raw accumulator of the previous layer" into the final
-// activation (bias + tanh + dropout, stash, head partial sums ...).  It is called ONE SLAB AHEAD
-// of its use, in the same scheduling region as the 128 MFMAs of slab kb-1, so its VALU / memory
-// work fills the shadow of those MFMAs instead of idling the matrix pipe between layers.
-template <int NBIN, int NBOUT, typename F>
-__device__ __forceinline__ void layer_forward_lazy(f32x16 (&acc)[NBOUT], const f32x16 (&h)[NBIN], Pipe& pipe, int lane,
-                                                   F&& prep) {
-  const int hh = lane >> 5, i = lane & 31;
+// out^T[f2][n] += sum_f W[f2][f] h^T[f][n]; one forward slab (32 input features = 2 blocks) per step.
+// Output tiles are walked in pairs so consecutive MFMAs hit different accumulators (the
+// 16x16x4 form has 40-cycle dependent latency against a 32-cycle issue interval).
+template <int NTIN, int NTOUT>
+__device__ __forceinline__ void layer_forward(f32x4 (&acc)[NTOUT], const f32x4 (&h)[NTIN], Pipe& pipe, int lane) {
+  const int kq = lane >> 4, i = lane & 15;
   const int sw = (i >> 1) & 7;
   const int base = i * 128;
-  prep(0);
 #pragma unroll
-  for (int kb = 0; kb < NBIN; ++kb) {
-    if (kb + 1 < NBIN) prep(kb + 1);
+  for (int kb = 0; kb < NTIN / 2; ++kb) {
     const char* buf = pipe.cur() + base;
-    // A fragments (16 B = four k-steps of one 32x32 output tile) are fetched kAhead groups before use
-    constexpr int kGroups = 4 * NBOUT, kAhead = 2;
-    f32x4 afrag[kAhead + 1];
 #pragma unroll
-    for (int p = 0; p < kAhead; ++p)
-      afrag[p] = *reinterpret_cast<const f32x4*>(buf + (((2 * (p / NBOUT) + hh) ^ sw) << 4) + (p % NBOUT) * 4096);
+    for (int half = 0; half < 2; ++half) {
+      const int off = ((4 * half + kq) ^ sw) << 4;
+      const f32x4 b = h[2 * kb + half];
 #pragma unroll
-    for (int gi = 0; gi < kGroups; ++gi) {
-      const int g = gi / NBOUT, mt = gi % NBOUT;
-      if (gi + kAhead < kGroups) {
-        const int gn = (gi + kAhead) / NBOUT, mn = (gi + kAhead) % NBOUT;
-        afrag[(gi + kAhead) % (kAhead + 1)] = *reinterpret_cast<const f32x4*>(buf + (((2 * gn + hh) ^ sw) << 4) + mn * 4096);
-      }
-      const f32x4 a = afrag[gi % (kAhead + 1)];
-      acc[mt] = PINN_MFMA(a[0], h[kb][4 * g + 0], acc[mt]);
-      acc[mt] = PINN_MFMA(a[1], h[kb][4 * g + 1], acc[mt]);
-      acc[mt] = PINN_MFMA(a[2], h[kb][4 * g + 2], acc[mt]);
-      acc[mt] = PINN_MFMA(a[3], h[kb][4 * g + 3], acc[mt]);
-    }
-    pipe.advance();
-  }
-}
-
-// Backward (dgrad) layer with lazy operand preparation:
-//   din^T[f][n] += sum_f2 W[f2][f] dpre^T[f2][n]; one backward slab (32 rows of W) per dpre block.
-template <int NBK, int NBOUT, typename F>
-__device__ __forceinline__ void layer_backward_lazy(f32x16 (&acc)[NBOUT], const f32x16 (&dpre)[NBK], Pipe& pipe, int lane,
-                                                    int ld, F&& prep) {
-  const int hh = lane >> 5, i = lane & 31;
-  prep(0);
-#pragma unroll
-  for (int kb = 0; kb < NBK; ++kb) {
-    if (kb + 1 < NBK) prep(kb + 1);
-    const float* buf = reinterpret_cast<const float*>(pipe.cur()) + i;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float* row = buf + (8 * g + 4 * hh) * ld;
-#pragma unroll
-      for (int mt = 0; mt < NBOUT; ++mt) {
-        acc[mt] = PINN_MFMA(row[mt * 32], dpre[kb][4 * g + 0], acc[mt]);
-        acc[mt] = PINN_MFMA(row[mt * 32 + ld], dpre[kb][4 * g + 1], acc[mt]);
-        acc[mt] = PINN_MFMA(row[mt * 32 + 2 * ld], dpre[kb][4 * g + 2], acc[mt]);
-        acc[mt] = PINN_MFMA(row[mt * 32 + 3 * ld], dpre[kb][4 * g + 3], acc[mt]);
+      for (int mt = 0; mt < NTOUT; mt += 2) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(buf + off + mt * 2048);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(buf + off + (mt + 1) * 2048);
+        acc[mt] = PINN_MFMA16(a0[0], b[0], acc[mt]);
+        acc[mt + 1] = PINN_MFMA16(a1[0], b[0], acc[mt + 1]);
+        acc[mt] = PINN_MFMA16(a0[1], b[1], acc[mt]);
+        acc[mt + 1] = PINN_MFMA16(a1[1], b[1], acc[mt + 1]);
+        acc[mt] = PINN_MFMA16(a0[2], b[2], acc[mt]);
+        acc[mt + 1] = PINN_MFMA16(a1[2], b[2], acc[mt + 1]);
+        acc[mt] = PINN_MFMA16(a0[3], b[3], acc[mt]);
+        acc[mt + 1] = PINN_MFMA16(a1[3], b[3], acc[mt + 1]);
       }
     }
     pipe.advance();
   }
 }
 
-// input layer: acc = W0 x^T (bias added by the lazy activation), W0 [H, 8] read straight from global
-template <int NBOUT>
-__device__ __forceinline__ void layer_input(f32x16 (&acc)[NBOUT], const float* __restrict__ W0, const f32x4& xa,
-                                            const f32x4& xb, int lane) {
-  const int hh = lane >> 5, i = lane & 31;
-  const float x0 = hh ? xa[1] : xa[0], x1 = hh ? xa[3] : xa[2], x2 = hh ? xb[1] : xb[0], x3 = hh ? xb[3] : xb[2];
+// din^T[f][n] += sum_f2 W[f2][f] dpre^T[f2][n]; one backward slab (32 rows of W = 2 dpre blocks) per step
+template <int NTK, int NTOUT>
+__device__ __forceinline__ void layer_backward(f32x4 (&acc)[NTOUT], const f32x4 (&dpre)[NTK], Pipe& pipe, int lane, int ld) {
+  const int kq = lane >> 4, i = lane & 15;
+  const int flip = kq & 1;
 #pragma unroll
-  for (int mt = 0; mt < NBOUT; ++mt) {
-    const f32x4 wa = *reinterpret_cast<const f32x4*>(W0 + (mt * 32 + i) * 8);
-    const f32x4 wb = *reinterpret_cast<const f32x4*>(W0 + (mt * 32 + i) * 8 + 4);
-    f32x16 c;
+  for (int kb = 0; kb < NTK / 2; ++kb) {
+    const float* buf = reinterpret_cast<const float*>(pipe.cur());
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c[r] = 0.0f;
-    c = PINN_MFMA(hh ? wa[1] : wa[0], x0, c);
-    c = PINN_MFMA(hh ? wa[3] : wa[2], x1, c);
-    c = PINN_MFMA(hh ? wb[1] : wb[0], x2, c);
-    c = PINN_MFMA(hh ? wb[3] : wb[2], x3, c);
+    for (int half = 0; half < 2; ++half) {
+      const float* row = buf + (16 * half + 4 * kq) * ld + i;
+      const f32x4 b = dpre[2 * kb + half];
+#pragma unroll
+      for (int mt = 0; mt < NTOUT; mt += 2) {
+        const float* c0 = row + ((mt ^ flip) << 4);
+        const float* c1 = row + (((mt + 1) ^ flip) << 4);
+        acc[mt] = PINN_MFMA16(c0[0], b[0], acc[mt]);
+        acc[mt + 1] = PINN_MFMA16(c1[0], b[0], acc[mt + 1]);
+        acc[mt] = PINN_MFMA16(c0[ld], b[1], acc[mt]);
+        acc[mt + 1] = PINN_MFMA16(c1[ld], b[1], acc[mt + 1]);
+        acc[mt] = PINN_MFMA16(c0[2 * ld], b[2], acc[mt]);
+        acc[mt + 1] = PINN_MFMA16(c1[2 * ld], b[2], acc[mt + 1]);
+        acc[mt] = PINN_MFMA16(c0[3 * ld], b[3], acc[mt]);
+        acc[mt + 1] = PINN_MFMA16(c1[3 * ld], b[3], acc[mt + 1]);
+      }
+    }
+    pipe.advance();
+  }
+}
+
+// input layer: acc = b0 + W0 x^T; W0 [H, 8] straight from global (8 KB, cache resident).
+// k-step t contracts inputs {4t + kq}.
+template <int NTOUT>
+__device__ __forceinline__ void layer_input(f32x4 (&acc)[NTOUT], const float* __restrict__ W0, const float* __restrict__ b0,
+                                            const f32x4& xa, const f32x4& xb, int lane) {
+  const int kq = lane >> 4, i = lane & 15;
+  const float x0 = kq == 0 ? xa[0] : (kq == 1 ? xa[1] : (kq == 2 ? xa[2] : xa[3]));
+  const float x1 = kq == 0 ? xb[0] : (kq == 1 ? xb[1] : (kq == 2 ? xb[2] : xb[3]));
+#pragma unroll
+  for (int mt = 0; mt < NTOUT; ++mt) {
+    const float w0 = W0[(mt * 16 + i) * 8 + kq];
+    const float w1 = W0[(mt * 16 + i) * 8 + 4 + kq];
+    f32x4 c = *reinterpret_cast<const f32x4*>(b0 + mt * 16 + 4 * kq);
+    c = PINN_MFMA16(w0, x0, c);
+    c = PINN_MFMA16(w1, x1, c);
     acc[mt] = c;
   }
 }
 
-// one 32-feature block: v = dropout(tanh(v + bias)); returns the 16 keep bits.  Branch-free.
+// v = dropout(tanh(v)) for the 32-feature group fp (blocks 2fp, 2fp+1); returns its 8 keep bits
 template <bool kBits>
-__device__ __forceinline__ unsigned activate_block(f32x16& v, const float* __restrict__ bias32, const DropDev& d,
-                                                   const RowCtx& c, int layer, int fb, bool has_drop) {
-  const bool drop = has_drop && c.mode != PINN_DROP_NONE;
+__device__ __forceinline__ unsigned activate_pair(f32x4& v0, f32x4& v1, const DropDev& d, const RowCtx& c, int layer, int fp) {
+  const bool drop = c.mode != PINN_DROP_NONE;
   const unsigned thr = drop ? d.thr[layer] : 0u;
   const float scale = drop ? d.scale[layer] : 1.0f;
-  const unsigned keep = keep_bits<kBits>(d, thr, layer, fb, c.hh, c.grow, c.lrow, c.n_rows, c.pass);
+  const unsigned keep = keep_bits8<kBits>(d, c, thr, layer, fp);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(bias32 + 8 * q + 4 * c.hh);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = 4 * q + j;
-      const float a = tanh_f32(v[r] + b[j]);
-      v[r] = ((keep >> r) & 1u) ? a * scale : 0.0f;
-    }
+  for (int r = 0; r < 4; ++r) {
+    const float a0 = tanh_f32(v0[r]);
+    const float a1 = tanh_f32(v1[r]);
+    v0[r] = ((keep >> r) & 1u) ? a0 * scale : 0.0f;
+    v1[r] = ((keep >> (4 + r)) & 1u) ? a1 * scale : 0.0f;
   }
   return keep;
 }
 
 // tanh only (no dropout module after this layer)
-__device__ __forceinline__ void activate_block_tanh(f32x16& v, const float* __restrict__ bias32, int hh) {
+__device__ __forceinline__ void activate_tanh(f32x4& v) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(bias32 + 8 * q + 4 * hh);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[4 * q + j] = tanh_f32(v[4 * q + j] + b[j]);
-  }
+  for (int r = 0; r < 4; ++r) v[r] = tanh_f32(v[r]);
 }
 
-// partial <w, h> over one block (this lane's 16 features)
-__device__ __forceinline__ float block_dot(const f32x16& h, const float* __restrict__ w32, int hh, float s) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const f32x4 wv = *reinterpret_cast<const f32x4*>(w32 + 8 * q + 4 * hh);
-    s = fmaf(wv[0], h[4 * q + 0], s);
-    s = fmaf(wv[1], h[4 * q + 1], s);
-    s = fmaf(wv[2], h[4 * q + 2], s);
-    s = fmaf(wv[3], h[4 * q + 3], s);
-  }
+// partial <w, h> over one block (this lane's 4 features)
+__device__ __forceinline__ float block_dot(const f32x4& h, const float* __restrict__ w16, int kq, float s) {
+  const f32x4 w = *reinterpret_cast<const f32x4*>(w16 + 4 * kq);
+  s = fmaf(w[0], h[0], s);
+  s = fmaf(w[1], h[1], s);
+  s = fmaf(w[2], h[2], s);
+  s = fmaf(w[3], h[3], s);
+  return s;
+}
+// complete a per-lane partial over the four kq lane groups (all lanes get the total)
+__device__ __forceinline__ float sum_kq(float s) {
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
   return s;
 }
 
-// element (feature f, row n) of 32-row tile `tile32` of an F-feature tensor lives at ((tile32*F + f)*32 + n):
-// one block = 16 dword accesses per lane, each wave-instruction two contiguous 128-B segments
-__device__ __forceinline__ float* tiled_block_ptr(float* base, long long tile32, int F, int fb, int lane) {
-  return base + (tile32 * F + fb * 32 + 4 * (lane >> 5)) * 32 + (lane & 31);
+// element (feature f, row n) of 16-row tile `t16` of an F-feature tensor lives at ((t16*F + f)*16 + n):
+// one block = 4 dword accesses per lane, each wave-instruction four contiguous 64-B segments
+__device__ __forceinline__ float* tiled_ptr(float* base, long long t16, int F, int lane) {
+  return base + (t16 * F + 4 * (lane >> 4)) * 16 + (lane & 15);
 }
-__device__ __forceinline__ void store_block(float* __restrict__ p, const f32x16& v) {
+__device__ __forceinline__ void store_block(float* __restrict__ p, int ib, const f32x4& v) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * 32] = v[r];
+  for (int r = 0; r < 4; ++r) p[(ib * 16 + r) * 16] = v[r];
 }
-__device__ __forceinline__ void load_block(const float* __restrict__ p, f32x16& v) {
+__device__ __forceinline__ void load_block(const float* __restrict__ p, int ib, f32x4& v) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = p[((r & 3) + 8 * (r >> 2)) * 32];
+  for (int r = 0; r < 4; ++r) v[r] = p[(ib * 16 + r) * 16];
 }
 
 // logvar = log(softplus(z) + 1e-6), softplus with torch's threshold 20 (01:432-434)
 __device__ __forceinline__ float softplus_f32(float z) { return z > 20.0f ? z : log1pf(expf(z)); }
 
 // ---------------------------------------------------------------------------------------
-// One forward pass of the whole net for this wave's 32 rows -> (u, z); both lane halves hold them.
-// TRAIN: also parks the keep bits in LDS (keep[(module*NB + block)*64]) and writes the
-// post-dropout activations to the tiled stash.
+// One forward pass of the whole net for this wave's 16 rows -> (u, z); every lane holds them.
+// TRAIN: also writes the keep bits (one byte per 32-feature group and lane) and the post-dropout
+// activations to the tiled stash.
 // ---------------------------------------------------------------------------------------
 struct StashPtrs {
-  float* h;        // [nh][T32][H][32]
-  float* v1;       // [T32][H/2][32]
-  float* v2;       // [T32][H/4][32]
-  long long t32_total;
-  long long tile32;
-  unsigned short* keep;   // this lane's LDS slot base
+  float* h;                // [nh][T16][H][16]
+  float* v1;               // [T16][H/2][16]
+  float* v2;               // [T16][H/4][16]
+  unsigned char* keep;     // [T16][nh*H/32 + H/64][64]
+  long long t16_total;
+  long long t16;
 };
 
 template <int H, bool TRAIN, bool kBits>
 __device__ __forceinline__ void forward_pass(const float* __restrict__ P, const ParamLayout& L, Pipe& pipe, const DropDev& d,
                                              const RowCtx& c, const f32x4& xa, const f32x4& xb, const StashPtrs& st, float& u,
-                                             float& z, f32x16 (&v2)[H / 128]) {
-  constexpr int NB = H / 32, NB2 = H / 64, NB4 = H / 128;
-  const int lane = c.lane, hh = c.hh;
-  f32x16 h[NB];
-  layer_input<NB>(h, P + L.w0(), xa, xb, lane);
-  // hidden layers 1 .. nh-1: while layer l's slabs multiply, layer l-1's raw output is activated block by block
+                                             float& z, f32x4 (&v2)[H / 64]) {
+  constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32;
+  const int lane = c.lane, kq = c.kq;
+  const int n_groups = L.nh * NP + NP / 2;
+  unsigned char* keep = TRAIN ? st.keep + (st.t16 * n_groups) * 64 + lane : nullptr;
+  f32x4 h[NT];
+  layer_input<NT>(h, P + L.w0(), P + L.b0(), xa, xb, lane);
 #pragma unroll 1
-  for (int l = 1; l < L.nh; ++l) {
-    f32x16 acc[NB];
-    zero_blocks<NB>(acc);
-    const float* bias = P + (l == 1 ? L.b0() : L.b(l - 1));
-    layer_forward_lazy<NB, NB>(acc, h, pipe, lane, [&](int kb) {
-      const unsigned keep = activate_block<kBits>(h[kb], bias + kb * 32, d, c, l - 1, kb, true);
-      if (TRAIN) {
-        st.keep[((l - 1) * NB + kb) * 64] = (unsigned short)keep;
-        store_block(tiled_block_ptr(st.h + (long long)(l - 1) * st.t32_total * H * 32, st.tile32, H, kb, lane), h[kb]);
-      }
-    });
+  for (int l = 0; l < L.nh; ++l) {
+    // activation of hidden layer l
+    float* sp = TRAIN ? tiled_ptr(st.h + (long long)l * st.t16_total * H * 16, st.t16, H, lane) : nullptr;
 #pragma unroll
-    for (int mt = 0; mt < NB; ++mt) h[mt] = acc[mt];
-  }
-  // h = raw output of the last hidden layer; its activation + the predict head ride on the variance head's first layer
-  f32x16 v1[NB2];
-  zero_blocks<NB2>(v1);
-  float up = 0.0f;
-  {
-    const int ll = L.nh - 1;
-    const float* bias = P + (ll == 0 ? L.b0() : L.b(ll));
-    layer_forward_lazy<NB, NB2>(v1, h, pipe, lane, [&](int kb) {
-      const unsigned keep = activate_block<kBits>(h[kb], bias + kb * 32, d, c, ll, kb, true);
-      up = block_dot(h[kb], P + L.wp() + kb * 32, hh, up);
+    for (int fp = 0; fp < NP; ++fp) {
+      const unsigned k8 = activate_pair<kBits>(h[2 * fp], h[2 * fp + 1], d, c, l, fp);
       if (TRAIN) {
-        st.keep[(ll * NB + kb) * 64] = (unsigned short)keep;
-        store_block(tiled_block_ptr(st.h + (long long)ll * st.t32_total * H * 32, st.tile32, H, kb, lane), h[kb]);
+        keep[(l * NP + fp) * 64] = (unsigned char)k8;
+        store_block(sp, 2 * fp, h[2 * fp]);
+        store_block(sp, 2 * fp + 1, h[2 * fp + 1]);
       }
-    });
-  }
-  u = up + __shfl_xor(up, 32, 64) + P[L.bp()];
-  zero_blocks<NB4>(v2);
-  layer_forward_lazy<NB2, NB4>(v2, v1, pipe, lane, [&](int kb) {
-    const unsigned keep = activate_block<kBits>(v1[kb], P + L.bv0() + kb * 32, d, c, L.nh, kb, true);
-    if (TRAIN) {
-      st.keep[(L.nh * NB + kb) * 64] = (unsigned short)keep;
-      store_block(tiled_block_ptr(st.v1, st.tile32, H / 2, kb, lane), v1[kb]);
     }
-  });
-  float zp = 0.0f;
+    if (l + 1 < L.nh) {
+      f32x4 acc[NT];
+      bias_blocks<NT>(acc, P + L.b(l + 1), kq);
+      layer_forward<NT, NT>(acc, h, pipe, lane);
 #pragma unroll
-  for (int mt = 0; mt < NB4; ++mt) {
-    activate_block_tanh(v2[mt], P + L.bv1() + mt * 32, hh);
-    zp = block_dot(v2[mt], P + L.wv2() + mt * 32, hh, zp);
-    if (TRAIN) store_block(tiled_block_ptr(st.v2, st.tile32, H / 4, mt, lane), v2[mt]);
+      for (int t = 0; t < NT; ++t) h[t] = acc[t];
+    }
   }
-  z = zp + __shfl_xor(zp, 32, 64) + P[L.bv2()];
+  // heads: predict (H -> 1) on the VALU, variance head on the matrix cores
+  float up = 0.0f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) up = block_dot(h[t], P + L.wp() + t * 16, kq, up);
+  u = sum_kq(up) + P[L.bp()];
+  f32x4 v1[NT2];
+  bias_blocks<NT2>(v1, P + L.bv0(), kq);
+  layer_forward<NT, NT2>(v1, h, pipe, lane);
+  {
+    float* sp = TRAIN ? tiled_ptr(st.v1, st.t16, H / 2, lane) : nullptr;
+#pragma unroll
+    for (int fp = 0; fp < NP / 2; ++fp) {
+      const unsigned k8 = activate_pair<kBits>(v1[2 * fp], v1[2 * fp + 1], d, c, L.nh, fp);
+      if (TRAIN) {
+        keep[(L.nh * NP + fp) * 64] = (unsigned char)k8;
+        store_block(sp, 2 * fp, v1[2 * fp]);
+        store_block(sp, 2 * fp + 1, v1[2 * fp + 1]);
+      }
+    }
+  }
+  bias_blocks<NT4>(v2, P + L.bv1(), kq);
+  layer_forward<NT2, NT4>(v2, v1, pipe, lane);
+  float zp = 0.0f;
+  {
+    float* sp = TRAIN ? tiled_ptr(st.v2, st.t16, H / 4, lane) : nullptr;
+#pragma unroll
+    for (int t = 0; t < NT4; ++t) {
+      activate_tanh(v2[t]);
+      zp = block_dot(v2[t], P + L.wv2() + t * 16, kq, zp);
+      if (TRAIN) store_block(sp, t, v2[t]);
+    }
+  }
+  z = sum_kq(zp) + P[L.bv2()];
 }
 
 }  // namespace pinn
