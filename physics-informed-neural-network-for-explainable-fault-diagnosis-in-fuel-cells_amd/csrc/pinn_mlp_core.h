@@ -156,15 +156,11 @@ struct Pipe {
   __device__ __forceinline__ void issue(int idx) {
     pending = tab[idx];
     const int tid = threadIdx.x;
-    const float* g;
-    long long gstride;
-    if (pending.kind == 0) {
-      g = params + pending.off + (long long)(tid >> 3) * pending.ld + (tid & 7) * 4;
-      gstride = 32LL * pending.ld;
-    } else {
-      g = params + pending.off + tid * 4;
-      gstride = 1024;
-    }
+    const int fwd_mask = -(int)(pending.kind == 0);
+    const int o_f = (tid >> 3) * (int)pending.ld + (tid & 7) * 4, o_b = tid * 4;
+    const int s_f = 32 * (int)pending.ld, s_b = 1024;
+    const float* g = params + pending.off + (((o_f ^ o_b) & fwd_mask) ^ o_b);
+    const int gstride = ((s_f ^ s_b) & fwd_mask) ^ s_b;
     const int last = pending.np - 1;
 #pragma unroll
     for (int p = 0; p < 8; ++p) regs[p] = *reinterpret_cast<const f32x4*>(g + (p < last ? p : last) * gstride);
@@ -178,13 +174,14 @@ struct Pipe {
     // bit 2 set (kq odd in the reader) get column bit 4 flipped -> conflict-free ds_read_b32.
     const int fwd_off = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
     const int sh = 31 - __clz((int)pending.ld) - 2;        // log2(ld / 4)
-    const bool fwd = pending.kind == 0;
+    const int fwd_mask = -(int)(pending.kind == 0);
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int pp = p < last ? p : last;
       const int idx = pp * 256 + tid;
       const int bwd_off = (idx * 16) ^ ((((idx >> sh) >> 2) & 1) << 6);
-      *reinterpret_cast<f32x4*>(dst + (fwd ? fwd_off + pp * 4096 : bwd_off)) = regs[p];
+      const int off = (((fwd_off + pp * 4096) ^ bwd_off) & fwd_mask) ^ bwd_off;   // bit-select: a branch here splits the region
+      *reinterpret_cast<f32x4*>(dst + off) = regs[p];
     }
   }
   // stage slab 0 synchronously, then start fetching slab 1
@@ -263,23 +260,31 @@ __device__ __forceinline__ void layer_forward(f32x4 (&acc)[NTOUT], const f32x4 (
 #pragma unroll
   for (int kb = 0; kb < NTIN / 2; ++kb) {
     const char* buf = pipe.cur() + base;
+    // flat list of (half, output-tile pair) groups; the A fragments of group g+1 are requested before the
+    // eight MFMAs of group g issue, so the ~100-cycle LDS latency sits under 256 cycles of matrix work
+    constexpr int kPairs = NTOUT / 2, kGroups = 2 * kPairs;
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(buf + (((0 + kq) ^ sw) << 4));
+    f32x4 a1 = *reinterpret_cast<const f32x4*>(buf + (((0 + kq) ^ sw) << 4) + 2048);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int off = ((4 * half + kq) ^ sw) << 4;
-      const f32x4 b = h[2 * kb + half];
-#pragma unroll
-      for (int mt = 0; mt < NTOUT; mt += 2) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(buf + off + mt * 2048);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(buf + off + (mt + 1) * 2048);
-        acc[mt] = PINN_MFMA16(a0[0], b[0], acc[mt]);
-        acc[mt + 1] = PINN_MFMA16(a1[0], b[0], acc[mt + 1]);
-        acc[mt] = PINN_MFMA16(a0[1], b[1], acc[mt]);
-        acc[mt + 1] = PINN_MFMA16(a1[1], b[1], acc[mt + 1]);
-        acc[mt] = PINN_MFMA16(a0[2], b[2], acc[mt]);
-        acc[mt + 1] = PINN_MFMA16(a1[2], b[2], acc[mt + 1]);
-        acc[mt] = PINN_MFMA16(a0[3], b[3], acc[mt]);
-        acc[mt + 1] = PINN_MFMA16(a1[3], b[3], acc[mt + 1]);
+    for (int g = 0; g < kGroups; ++g) {
+      const int half = g / kPairs, mt = 2 * (g % kPairs);
+      f32x4 n0 = a0, n1 = a1;
+      if (g + 1 < kGroups) {
+        const int hn = (g + 1) / kPairs, mn = 2 * ((g + 1) % kPairs);
+        const int offn = ((4 * hn + kq) ^ sw) << 4;
+        n0 = *reinterpret_cast<const f32x4*>(buf + offn + mn * 2048);
+        n1 = *reinterpret_cast<const f32x4*>(buf + offn + (mn + 1) * 2048);
       }
+      const f32x4 b = h[2 * kb + half];
+      acc[mt] = PINN_MFMA16(a0[0], b[0], acc[mt]);
+      acc[mt + 1] = PINN_MFMA16(a1[0], b[0], acc[mt + 1]);
+      acc[mt] = PINN_MFMA16(a0[1], b[1], acc[mt]);
+      acc[mt + 1] = PINN_MFMA16(a1[1], b[1], acc[mt + 1]);
+      acc[mt] = PINN_MFMA16(a0[2], b[2], acc[mt]);
+      acc[mt + 1] = PINN_MFMA16(a1[2], b[2], acc[mt + 1]);
+      acc[mt] = PINN_MFMA16(a0[3], b[3], acc[mt]);
+      acc[mt + 1] = PINN_MFMA16(a1[3], b[3], acc[mt + 1]);
+      a0 = n0; a1 = n1;
     }
     pipe.advance();
   }
@@ -335,11 +340,27 @@ __device__ __forceinline__ void layer_input(f32x4 (&acc)[NTOUT], const float* __
 }
 
 // v = dropout(tanh(v)) for the 32-feature group fp (blocks 2fp, 2fp+1); returns its 8 keep bits
+// per-layer dropout constants, resolved once outside the unrolled block loop (a select on a
+// kernel-argument load inside it turns into a branch per block)
+struct LayerDrop {
+  unsigned thr;
+  float scale;
+};
+__device__ __forceinline__ LayerDrop layer_drop(const DropDev& d, int mode, int layer) {
+  const unsigned on = mode != PINN_DROP_NONE ? 0xFFFFFFFFu : 0u;
+  const unsigned t = d.thr[layer];
+  const float s = d.scale[layer];
+  LayerDrop r;
+  r.thr = t & on;
+  r.scale = __uint_as_float((__float_as_uint(s) & on) | (0x3F800000u & ~on));
+  return r;
+}
+
 template <bool kBits>
-__device__ __forceinline__ unsigned activate_pair(f32x4& v0, f32x4& v1, const DropDev& d, const RowCtx& c, int layer, int fp) {
-  const bool drop = c.mode != PINN_DROP_NONE;
-  const unsigned thr = drop ? d.thr[layer] : 0u;
-  const float scale = drop ? d.scale[layer] : 1.0f;
+__device__ __forceinline__ unsigned activate_pair(f32x4& v0, f32x4& v1, const DropDev& d, const RowCtx& c, const LayerDrop ld,
+                                                  int layer, int fp) {
+  const unsigned thr = ld.thr;
+  const float scale = ld.scale;
   const unsigned keep = keep_bits8<kBits>(d, c, thr, layer, fp);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -417,10 +438,11 @@ __device__ __forceinline__ void forward_pass(const float* __restrict__ P, const 
 #pragma unroll 1
   for (int l = 0; l < L.nh; ++l) {
     // activation of hidden layer l
+    const LayerDrop ldr = layer_drop(d, c.mode, l);
     float* sp = TRAIN ? tiled_ptr(st.h + (long long)l * st.t16_total * H * 16, st.t16, H, lane) : nullptr;
 #pragma unroll
     for (int fp = 0; fp < NP; ++fp) {
-      const unsigned k8 = activate_pair<kBits>(h[2 * fp], h[2 * fp + 1], d, c, l, fp);
+      const unsigned k8 = activate_pair<kBits>(h[2 * fp], h[2 * fp + 1], d, c, ldr, l, fp);
       if (TRAIN) {
         keep[(l * NP + fp) * 64] = (unsigned char)k8;
         store_block(sp, 2 * fp, h[2 * fp]);
@@ -445,9 +467,10 @@ __device__ __forceinline__ void forward_pass(const float* __restrict__ P, const 
   layer_forward<NT, NT2>(v1, h, pipe, lane);
   {
     float* sp = TRAIN ? tiled_ptr(st.v1, st.t16, H / 2, lane) : nullptr;
+    const LayerDrop ldr = layer_drop(d, c.mode, L.nh);
 #pragma unroll
     for (int fp = 0; fp < NP / 2; ++fp) {
-      const unsigned k8 = activate_pair<kBits>(v1[2 * fp], v1[2 * fp + 1], d, c, L.nh, fp);
+      const unsigned k8 = activate_pair<kBits>(v1[2 * fp], v1[2 * fp + 1], d, c, ldr, L.nh, fp);
       if (TRAIN) {
         keep[(L.nh * NP + fp) * 64] = (unsigned char)k8;
         store_block(sp, 2 * fp, v1[2 * fp]);

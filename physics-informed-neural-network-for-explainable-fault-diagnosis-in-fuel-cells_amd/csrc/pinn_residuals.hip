@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxBlocks = 2048;   // 256 CUs x 8 resident workgroups; grid-stride beyond
+constexpr int kMaxBlocks = 1024;   // 256 CUs x 4 workgroups; grid-stride beyond
 
 struct AffineDev {
   double x_min[8];
@@ -61,14 +61,17 @@ __global__ __launch_bounds__(kThreads) void residuals_kernel(
   for (long long row = (long long)blockIdx.x * kThreads + threadIdx.x; row < n_rows; row += stride) {
     const float4 xa = reinterpret_cast<const float4*>(x)[row * 2];
     const float4 xb = reinterpret_cast<const float4*>(x)[row * 2 + 1];
-    const float r0 = denorm(xa.x, aff.x_min[0], aff.x_scale[0]);   // I [A]
-    const float r1 = denorm(xa.y, aff.x_min[1], aff.x_scale[1]);   // coolant flow
-    const float r2 = denorm(xa.z, aff.x_min[2], aff.x_scale[2]);   // T_in
-    const float r3 = denorm(xa.w, aff.x_min[3], aff.x_scale[3]);   // P_H2
-    const float r4 = denorm(xb.x, aff.x_min[4], aff.x_scale[4]);   // P_air
-    const float r5 = denorm(xb.y, aff.x_min[5], aff.x_scale[5]);   // T_out
-    const float r6 = denorm(xb.z, aff.x_min[6], aff.x_scale[6]);   // H2 flow
-    const float r7 = denorm(xb.w, aff.x_min[7], aff.x_scale[7]);   // air flow
+    // the float64 divide of the sklearn-exact de-normalisation is the most expensive op of the pass:
+    // only the columns the requested residuals read are de-normalised (flags is wave-uniform)
+    const bool fV = flags & PINN_RES_V, fT = flags & PINN_RES_T, fH = flags & PINN_RES_H, fO = flags & PINN_RES_O;
+    const float r0 = denorm(xa.x, aff.x_min[0], aff.x_scale[0]);                    // I [A]
+    const float r1 = fT ? denorm(xa.y, aff.x_min[1], aff.x_scale[1]) : 0.f;         // coolant flow
+    const float r2 = fT ? denorm(xa.z, aff.x_min[2], aff.x_scale[2]) : 0.f;         // T_in
+    const float r3 = fV ? denorm(xa.w, aff.x_min[3], aff.x_scale[3]) : 0.f;         // P_H2
+    const float r4 = fV ? denorm(xb.x, aff.x_min[4], aff.x_scale[4]) : 0.f;         // P_air
+    const float r5 = (fV || fT) ? denorm(xb.y, aff.x_min[5], aff.x_scale[5]) : 0.f; // T_out
+    const float r6 = fH ? denorm(xb.z, aff.x_min[6], aff.x_scale[6]) : 0.f;         // H2 flow
+    const float r7 = fO ? denorm(xb.w, aff.x_min[7], aff.x_scale[7]) : 0.f;         // air flow
     const float yv = (y != nullptr) ? y[row] : 0.0f;
 
     const float i5 = r0 / 270.0f + 1e-5f;        // 01:730, 639, 553
@@ -207,19 +210,27 @@ __global__ __launch_bounds__(kThreads) void residuals_kernel(
   }
 }
 
-// fixed-order final reduction: thread (s, j) sums partials j, j+8, ... then 8 -> 1 in LDS order
-__global__ __launch_bounds__(256) void residuals_finalize(const double* __restrict__ partials, int n_blocks,
-                                                          double* __restrict__ sums) {
-  __shared__ double red[8][PINN_NSUMS];
+// fixed-order final reduction: thread (s, j) sums partials j, j+32, ... then lane s adds the 32 j-sums in order
+__global__ __launch_bounds__(1024) void residuals_finalize(const double* __restrict__ partials, int n_blocks,
+                                                           double* __restrict__ sums) {
+  __shared__ double red[32][PINN_NSUMS + 1];
   const int s = threadIdx.x & 31, j = threadIdx.x >> 5;
+  // all loads first (independent addresses), then the adds in fixed order: not a latency-bound chain
+  double v[kMaxBlocks / 32];
+#pragma unroll
+  for (int k = 0; k < kMaxBlocks / 32; ++k) {
+    const int b = j + 32 * k;
+    v[k] = b < n_blocks ? partials[(long long)b * PINN_NSUMS + s] : 0.0;
+  }
   double t = 0.0;
-  for (int b = j; b < n_blocks; b += 8) t += partials[(long long)b * PINN_NSUMS + s];
+#pragma unroll
+  for (int k = 0; k < kMaxBlocks / 32; ++k) t += v[k];
   red[j][s] = t;
   __syncthreads();
   if (threadIdx.x < PINN_NSUMS) {
     double r = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) r += red[k][threadIdx.x];
+    for (int k = 0; k < 32; ++k) r += red[k][threadIdx.x];
     sums[threadIdx.x] = r;
   }
 }
@@ -330,7 +341,7 @@ extern "C" int pinn_residuals(const float* d_x, const float* d_u, const float* d
       hipLaunchKernelGGL(residuals_kernel<false>, dim3(blocks), dim3(kThreads), 0, st, d_x, d_u, d_y, a, d_lambda, flags,
                          n_rows, d_cols, ld, partials);
   }
-  if (d_sums) hipLaunchKernelGGL(residuals_finalize, dim3(1), dim3(256), 0, st, partials, blocks, d_sums);
+  if (d_sums) hipLaunchKernelGGL(residuals_finalize, dim3(1), dim3(1024), 0, st, partials, blocks, d_sums);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;
 }

@@ -381,8 +381,18 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
     const bool pad = (e > off_bp && e < off_bp + 4) || (e > off_bv2 && e < off_bv2 + 4);
     if (e != off_bp && e != off_bv2) {
       float s = 0.0f;
-      if (!pad)
-        for (int k = 0; k < n_slices; ++k) s += slabs[(long long)k * total + e];
+      if (!pad) {
+        // 16 independent loads in flight, added in slice order (fixed order -> bitwise reproducible)
+        int k = 0;
+        for (; k + 16 <= n_slices; k += 16) {
+          float v[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = slabs[(long long)(k + q) * total + e];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) s += v[q];
+        }
+        for (; k < n_slices; ++k) s += slabs[(long long)k * total + e];
+      }
       grads[e] = s;
     }
   }

@@ -35,7 +35,7 @@ def test_header_symbols_exported_and_bound(lib):
 def test_host_only_entry_points(lib):
     from pinn_amd import _lib, layout
     assert lib.pinn_abi_version() == 1
-    assert lib.pinn_residuals_workspace_bytes() == 2048 * 32 * 8
+    assert lib.pinn_residuals_workspace_bytes() == 1024 * 32 * 8
     for H, nh in ((256, 3), (128, 3), (256, 1), (128, 8)):
         net = _lib.Net(8, H, nh)
         offs, total = layout.param_offsets(8, H, nh)
