@@ -27,10 +27,11 @@ template <int H, bool MC, bool kBits>
 __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(FwdArgs a) {
   __shared__ __attribute__((aligned(16))) char lds_w[2 * kChunkBytes];
   __shared__ ChunkDesc tab[kMaxChunks];
+  __shared__ __attribute__((aligned(16))) float small[kMaxSmall];
   ParamLayout L{a.H, a.nh};
   const int n_chunks = (a.nh - 1) * (H / 32) + H / 32 + H / 64;
   if (threadIdx.x == 0) build_forward_chunks(tab, L, 0);
-  __syncthreads();
+  load_small_params(small, a.params, L);
   Pipe pipe;
   pipe.params = a.params; pipe.tab = tab; pipe.lds = lds_w; pipe.n = n_chunks;
   pipe.prime();
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(FwdArgs a) {
     f32x4 v2[H / 64];
     if (!MC) {
       float u, z;
-      forward_pass<H, false, kBits>(a.params, L, pipe, a.drop, c, xa, xb, st, u, z, v2);
+      forward_pass<H, false, kBits>(a.params, small, L, pipe, a.drop, c, xa, xb, st, u, z, v2);
       if (valid && lane < 16) {
         a.o0[lrow] = u;
         a.o1[lrow] = logf(softplus_f32(z) + 1e-6f);
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(FwdArgs a) {
         c.mode = (t < 0) ? PINN_DROP_NONE : a.drop.mode;
         c.pass = (unsigned)(t < 0 ? 0 : t);
         float u, z;
-        forward_pass<H, false, kBits>(a.params, L, pipe, a.drop, c, xa, xb, st, u, z, v2);
+        forward_pass<H, false, kBits>(a.params, small, L, pipe, a.drop, c, xa, xb, st, u, z, v2);
         if (t < 0) {
           u_eval = u;
         } else {

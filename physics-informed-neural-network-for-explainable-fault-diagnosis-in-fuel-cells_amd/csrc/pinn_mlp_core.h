@@ -57,6 +57,37 @@ struct ParamLayout {
   __host__ __device__ long long total() const { return bv2() + 4; }
 };
 
+// Small parameter vectors (all biases, the predict and final variance weight rows) are copied into
+// LDS once per launch: read per layer between MFMA phases, an L2-latency global load there is an
+// exposed stall, an LDS read is ~5x shorter.
+struct SmallLayout {
+  int H, nh;
+  __host__ __device__ int b(int l) const { return l * H; }
+  __host__ __device__ int bp() const { return nh * H; }
+  __host__ __device__ int bv0() const { return nh * H + 4; }
+  __host__ __device__ int bv1() const { return bv0() + H / 2; }
+  __host__ __device__ int bv2() const { return bv1() + H / 4; }
+  __host__ __device__ int wp() const { return bv2() + 4; }
+  __host__ __device__ int wv2() const { return wp() + H; }
+  __host__ __device__ int total() const { return wv2() + H / 4; }
+};
+constexpr int kMaxSmall = 8 * 256 + 4 + 128 + 64 + 4 + 256 + 64;
+
+__device__ __forceinline__ void load_small_params(float* __restrict__ sp, const float* __restrict__ P, const ParamLayout& L) {
+  const SmallLayout S{L.H, L.nh};
+  const int H = L.H, tid = threadIdx.x;
+  for (int l = 0; l < L.nh; ++l)
+    for (int i = tid; i < H; i += kThreads) sp[S.b(l) + i] = P[L.b(l) + i];
+  for (int i = tid; i < H; i += kThreads) sp[S.wp() + i] = P[L.wp() + i];
+  for (int i = tid; i < H / 2; i += kThreads) sp[S.bv0() + i] = P[L.bv0() + i];
+  for (int i = tid; i < H / 4; i += kThreads) {
+    sp[S.bv1() + i] = P[L.bv1() + i];
+    sp[S.wv2() + i] = P[L.wv2() + i];
+  }
+  if (tid == 0) { sp[S.bp()] = P[L.bp()]; sp[S.bv2()] = P[L.bv2()]; }
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------
 // dropout source (device copy of pinn_dropout_t)
 // ---------------------------------------------------------------------------------------
@@ -426,15 +457,16 @@ struct StashPtrs {
 };
 
 template <int H, bool TRAIN, bool kBits>
-__device__ __forceinline__ void forward_pass(const float* __restrict__ P, const ParamLayout& L, Pipe& pipe, const DropDev& d,
+__device__ __forceinline__ void forward_pass(const float* __restrict__ P, const float* smallp, const ParamLayout& L, Pipe& pipe, const DropDev& d,
                                              const RowCtx& c, const f32x4& xa, const f32x4& xb, const StashPtrs& st, float& u,
                                              float& z, f32x4 (&v2)[H / 64]) {
   constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32;
   const int lane = c.lane, kq = c.kq;
+  const SmallLayout S{L.H, L.nh};
   const int n_groups = L.nh * NP + NP / 2;
   unsigned char* keep = TRAIN ? st.keep + (st.t16 * n_groups) * 64 + lane : nullptr;
   f32x4 h[NT];
-  layer_input<NT>(h, P + L.w0(), P + L.b0(), xa, xb, lane);
+  layer_input<NT>(h, P + L.w0(), smallp + S.b(0), xa, xb, lane);
 #pragma unroll 1
   for (int l = 0; l < L.nh; ++l) {
     // activation of hidden layer l
@@ -451,7 +483,7 @@ __device__ __forceinline__ void forward_pass(const float* __restrict__ P, const 
     }
     if (l + 1 < L.nh) {
       f32x4 acc[NT];
-      bias_blocks<NT>(acc, P + L.b(l + 1), kq);
+      bias_blocks<NT>(acc, smallp + S.b(l + 1), kq);
       layer_forward<NT, NT>(acc, h, pipe, lane);
 #pragma unroll
       for (int t = 0; t < NT; ++t) h[t] = acc[t];
@@ -460,10 +492,10 @@ __device__ __forceinline__ void forward_pass(const float* __restrict__ P, const 
   // heads: predict (H -> 1) on the VALU, variance head on the matrix cores
   float up = 0.0f;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) up = block_dot(h[t], P + L.wp() + t * 16, kq, up);
-  u = sum_kq(up) + P[L.bp()];
+  for (int t = 0; t < NT; ++t) up = block_dot(h[t], smallp + S.wp() + t * 16, kq, up);
+  u = sum_kq(up) + smallp[S.bp()];
   f32x4 v1[NT2];
-  bias_blocks<NT2>(v1, P + L.bv0(), kq);
+  bias_blocks<NT2>(v1, smallp + S.bv0(), kq);
   layer_forward<NT, NT2>(v1, h, pipe, lane);
   {
     float* sp = TRAIN ? tiled_ptr(st.v1, st.t16, H / 2, lane) : nullptr;
@@ -478,7 +510,7 @@ __device__ __forceinline__ void forward_pass(const float* __restrict__ P, const 
       }
     }
   }
-  bias_blocks<NT4>(v2, P + L.bv1(), kq);
+  bias_blocks<NT4>(v2, smallp + S.bv1(), kq);
   layer_forward<NT2, NT4>(v2, v1, pipe, lane);
   float zp = 0.0f;
   {
@@ -486,11 +518,11 @@ __device__ __forceinline__ void forward_pass(const float* __restrict__ P, const 
 #pragma unroll
     for (int t = 0; t < NT4; ++t) {
       activate_tanh(v2[t]);
-      zp = block_dot(v2[t], P + L.wv2() + t * 16, kq, zp);
+      zp = block_dot(v2[t], smallp + S.wv2() + t * 16, kq, zp);
       if (TRAIN) store_block(sp, t, v2[t]);
     }
   }
-  z = sum_kq(zp) + P[L.bv2()];
+  z = sum_kq(zp) + smallp[S.bv2()];
 }
 
 }  // namespace pinn

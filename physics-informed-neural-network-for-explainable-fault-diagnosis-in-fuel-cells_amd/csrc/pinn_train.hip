@@ -60,14 +60,16 @@ __global__ __launch_bounds__(kThreads, 2) void train_chain_kernel(TrainArgs a) {
   __shared__ __attribute__((aligned(16))) char lds_w[2 * kChunkBytes];
   __shared__ ChunkDesc tab[kMaxChunks];
   __shared__ double red[4][kLossTerms];
+  __shared__ __attribute__((aligned(16))) float small[kMaxSmall];
   ParamLayout L{a.H, a.nh};
+  const SmallLayout S{a.H, a.nh};
   const int n_fwd = (a.nh - 1) * NP + NP + NP / 2;
   const int n_bwd = H / 128 + H / 64 + (a.nh - 1) * NP;
   if (threadIdx.x == 0) {
     int k = build_forward_chunks(tab, L, 0);
     build_backward_chunks(tab, L, k);
   }
-  __syncthreads();
+  load_small_params(small, a.params, L);
   Pipe pipe;
   pipe.params = a.params; pipe.tab = tab; pipe.lds = lds_w; pipe.n = n_fwd + n_bwd;
   pipe.prime();
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(kThreads, 2) void train_chain_kernel(TrainArgs a) {
     // ------------------------------------------------------------------ forward (stash + keep bits written)
     float u, z;
     f32x4 v2[NT4];
-    forward_pass<H, true, kBits>(P, L, pipe, a.drop, c, xa, xb, st, u, z, v2);
+    forward_pass<H, true, kBits>(P, small, L, pipe, a.drop, c, xa, xb, st, u, z, v2);
 
     // ------------------------------------------------------------------ aleatoric_loss (01:916-927) and its gradient
     float du = 0.f, dz = 0.f;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(kThreads, 2) void train_chain_kernel(TrainArgs a) {
         float* sp = tiled_ptr(a.dpre_v2, t16, H / 4, lane);
 #pragma unroll
         for (int t = 0; t < NT4; ++t) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(P + L.wv2() + t * 16 + 4 * kq);
+          const f32x4 w = *reinterpret_cast<const f32x4*>(small + S.wv2() + t * 16 + 4 * kq);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v2[t][r] = w[r] * dz * (1.0f - v2[t][r] * v2[t][r]);
           store_block(sp, t, v2[t]);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(kThreads, 2) void train_chain_kernel(TrainArgs a) {
       // d h_last = w_p * du + Wv0^T d pre_v1
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(P + L.wp() + t * 16 + 4 * kq);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(small + S.wp() + t * 16 + 4 * kq);
         dh[t] = w * du;
       }
       layer_backward<NT2, NT>(dh, dpv1, pipe, lane, H);
