@@ -204,8 +204,20 @@ def main():
     ms_wgrad = time_events(phase(2), reps)
     ms_reduce = time_events(phase(4), reps)
     achieved = CHAIN_FLOP_PER_ROW * rows / (ms_chain * 1e-3) / 1e12
+    # HBM bytes per launch of the chain kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    # WRITE_SIZE collected in separate runs at this workload size); null when the row count differs
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_summary_v2.json")
+    if rows == 1_000_000 and os.path.exists(pmc):
+        try:
+            k = [v for n, v in json.load(open(pmc)).items() if "train_chain_kernel" in n][0]
+            traffic = (k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
+            traffic_src = "profiles/r01/pmc_summary_v2.json: (FETCH_SIZE + WRITE_SIZE) KB x 1024, per launch, N=1e6; dword-per-lane " \
+                          "reads, so the 2x wide-read correction of FETCH_SIZE is not applied (uncalibrated, lower bound)"
+        except Exception:
+            pass
     out["roofline"] = {"kernel": "train_chain_kernel<256>", "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                       "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                       "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                        "flop_per_row": CHAIN_FLOP_PER_ROW, "ms": ms_chain,
                        "wgrad": {"ms": ms_wgrad, "achieved": FWD_FLOP_PER_ROW * rows / (ms_wgrad * 1e-3) / 1e12,
                                  "frac": FWD_FLOP_PER_ROW * rows / (ms_wgrad * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},

@@ -146,12 +146,16 @@ __global__ __launch_bounds__(kThreads, 2) void train_chain_kernel(TrainArgs a) {
         const float scale = drop ? a.drop.scale[L.nh] : 1.0f, inv_scale = 1.0f / scale;
         const float* hp = tiled_ptr(a.stash_v1, t16, H / 2, lane);
         float* sp = tiled_ptr(a.dpre_v1, t16, H / 2, lane);
+        // all stash loads first (independent addresses, one exposed latency), then the arithmetic
+        f32x4 hl[NT2];
+        unsigned kb[NP / 2];
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) load_block(hp, t, hl[t]);
+#pragma unroll
+        for (int fp = 0; fp < NP / 2; ++fp) kb[fp] = keep[(L.nh * NP + fp) * 64];
 #pragma unroll
         for (int fp = 0; fp < NP / 2; ++fp) {
-          f32x4 h0, h1;
-          load_block(hp, 2 * fp, h0);
-          load_block(hp, 2 * fp + 1, h1);
-          tanh_drop_backward_pair(dpv1[2 * fp], dpv1[2 * fp + 1], h0, h1, keep[(L.nh * NP + fp) * 64], scale, inv_scale);
+          tanh_drop_backward_pair(dpv1[2 * fp], dpv1[2 * fp + 1], hl[2 * fp], hl[2 * fp + 1], kb[fp], scale, inv_scale);
           store_block(sp, 2 * fp, dpv1[2 * fp]);
           store_block(sp, 2 * fp + 1, dpv1[2 * fp + 1]);
         }
@@ -172,12 +176,15 @@ __global__ __launch_bounds__(kThreads, 2) void train_chain_kernel(TrainArgs a) {
         const float scale = drop ? a.drop.scale[l] : 1.0f, inv_scale = 1.0f / scale;
         const float* hp = tiled_ptr(a.stash_h + (long long)l * a.t16 * H * 16, t16, H, lane);
         float* sp = tiled_ptr(a.dpre_h + (long long)l * a.t16 * H * 16, t16, H, lane);
+        f32x4 hl[NT];
+        unsigned kb[NP];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) load_block(hp, t, hl[t]);
+#pragma unroll
+        for (int fp = 0; fp < NP; ++fp) kb[fp] = keep[(l * NP + fp) * 64];
 #pragma unroll
         for (int fp = 0; fp < NP; ++fp) {
-          f32x4 h0, h1;
-          load_block(hp, 2 * fp, h0);
-          load_block(hp, 2 * fp + 1, h1);
-          tanh_drop_backward_pair(dh[2 * fp], dh[2 * fp + 1], h0, h1, keep[(l * NP + fp) * 64], scale, inv_scale);
+          tanh_drop_backward_pair(dh[2 * fp], dh[2 * fp + 1], hl[2 * fp], hl[2 * fp + 1], kb[fp], scale, inv_scale);
           store_block(sp, 2 * fp, dh[2 * fp]);
           store_block(sp, 2 * fp + 1, dh[2 * fp + 1]);
         }
