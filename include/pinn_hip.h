@@ -117,11 +117,19 @@ int pinn_lambda_step(int stage, const double* d_sums, long long n_global, float 
  *   W_0 b_0 ... W_{h-1} b_{h-1}  W_p b_p  Wv_0 bv_0  Wv_1 bv_1  Wv_2 bv_2
  * The fused kernels support hidden in {128, 256} (hidden % 128 == 0, <= 256), 1 <= n_hidden <= 8.
  */
+#define PINN_PREC_FP32 0  /* exact fp32 matrix math (default; parity with the reference at fp32 tolerance) */
+#define PINN_PREC_BF16 1  /* bf16 MFMA inputs, fp32 accumulate / activations / loss / master weights   */
+
 typedef struct pinn_net {
-  int n_in;      /* 8 */
-  int hidden;    /* H */
-  int n_hidden;  /* number of H-wide hidden layers (3 in the reference, 01:2139) */
+  int n_in;       /* 8 */
+  int hidden;     /* H */
+  int n_hidden;   /* number of H-wide hidden layers (3 in the reference, 01:2139) */
+  int precision;  /* PINN_PREC_* */
+  void* d_packed; /* PINN_PREC_BF16 only: device scratch of pinn_packed_bytes(net) bytes; every call re-packs the
+                     bf16 weight copies from d_params into it (stateless), NULL for fp32 */
 } pinn_net_t;
+
+size_t pinn_packed_bytes(const pinn_net_t* net);             /* 0 for fp32 / unsupported shapes */
 
 long long pinn_param_count(const pinn_net_t* net);          /* floats in the flat buffer, <0 on error */
 

@@ -159,8 +159,17 @@ def dropout_scale(p):
     return np.float32(1.0) / np.float32(1.0 - float(p))
 
 
-def mlp_forward(params, x, p_list=None, masks=None):
+def _bf(t):
+    """Round to bfloat16 and back (what a bf16 MFMA input sees)."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def mlp_forward(params, x, p_list=None, masks=None, bf16=False):
     """DNN.forward (01:421-438) with explicit keep-masks.
+
+    bf16=True restates the kernels' bf16/fp32-mixed policy (NOT the reference): inputs of the H x H,
+    H -> H/2 and H/2 -> H/4 products (weights and activations) are rounded to bfloat16, everything else
+    (first layer, accumulation, biases, tanh, dropout, both heads' final dot products) stays float32.
 
     params: list of tensors in `param_names` order; x [N, n_in] float32 tensor.
     masks: None (eval mode: dropout = identity) or list of n_hidden+1 bool/float arrays
@@ -168,20 +177,24 @@ def mlp_forward(params, x, p_list=None, masks=None):
     Returns (u [N,1], logvar [N,1]).
     """
     n_hidden = (len(params) - 8) // 2
+    q = _bf if bf16 else (lambda t: t)
     h = x
     for l in range(n_hidden):
-        a = torch.tanh(F.linear(h, params[2 * l], params[2 * l + 1]))
+        if l == 0:
+            a = torch.tanh(F.linear(h, params[0], params[1]))
+        else:
+            a = torch.tanh(F.linear(q(h), q(params[2 * l]), params[2 * l + 1]))
         if masks is not None:
             m = torch.as_tensor(np.asarray(masks[l]), dtype=torch.float32)
             a = a * (m * float(dropout_scale(p_list[l])))
         h = a
     k = 2 * n_hidden
     u = F.linear(h, params[k], params[k + 1])
-    v = torch.tanh(F.linear(h, params[k + 2], params[k + 3]))
+    v = torch.tanh(F.linear(q(h), q(params[k + 2]), params[k + 3]))
     if masks is not None:
         m = torch.as_tensor(np.asarray(masks[n_hidden]), dtype=torch.float32)
         v = v * (m * float(dropout_scale(p_list[n_hidden])))
-    v = torch.tanh(F.linear(v, params[k + 4], params[k + 5]))
+    v = torch.tanh(F.linear(q(v), q(params[k + 4]), params[k + 5]))
     z = F.linear(v, params[k + 6], params[k + 7])
     logvar = torch.log(F.softplus(z) + 1e-6)
     return u, logvar

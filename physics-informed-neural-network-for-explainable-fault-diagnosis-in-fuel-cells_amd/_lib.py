@@ -32,8 +32,14 @@ class Affine(ctypes.Structure):
                 ("y_scale", ctypes.c_double), ("vn_scale", c_float), ("vn_min", c_float)]
 
 
+PREC_FP32, PREC_BF16 = 0, 1
+
+
 class Net(ctypes.Structure):
-    _fields_ = [("n_in", c_int), ("hidden", c_int), ("n_hidden", c_int)]
+    _fields_ = [("n_in", c_int), ("hidden", c_int), ("n_hidden", c_int), ("precision", c_int), ("d_packed", c_void_p)]
+
+    def __init__(self, n_in=8, hidden=256, n_hidden=3, precision=0, d_packed=None):
+        super().__init__(n_in, hidden, n_hidden, precision, d_packed)
 
 
 class Dropout(ctypes.Structure):
@@ -52,6 +58,7 @@ _SIGS = {
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "pinn_lambda_step": (c_int, [c_int, c_void_p, c_ll, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pinn_param_count": (c_ll, [ctypes.POINTER(Net)]),
+    "pinn_packed_bytes": (c_size_t, [ctypes.POINTER(Net)]),
     "pinn_mlp_forward": (c_int, [ctypes.POINTER(Net), c_void_p, c_void_p, c_ll, ctypes.POINTER(Dropout), c_void_p, c_void_p,
                                  c_void_p]),
     "pinn_mc_dropout": (c_int, [ctypes.POINTER(Net), c_void_p, c_void_p, c_ll, ctypes.POINTER(Dropout), c_int, c_void_p,

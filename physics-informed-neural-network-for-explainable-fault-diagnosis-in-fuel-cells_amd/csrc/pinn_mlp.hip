@@ -11,18 +11,6 @@
 
 namespace pinn {
 
-struct FwdArgs {
-  const float* params;
-  const float* x;
-  long long n_rows;
-  int H, nh;
-  DropDev drop;
-  int n_passes;          // MC only
-  float* o0;             // forward: u        | MC: pred_mean
-  float* o1;             // forward: logvar   | MC: a_u
-  float* o2;             //                   | MC: e_u
-};
-
 template <int H, bool MC, bool kBits>
 __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(FwdArgs a) {
   __shared__ __attribute__((aligned(16))) char lds_w[2 * kChunkBytes];
@@ -118,6 +106,8 @@ static int check_net(const pinn_net_t* net) {
   if (net->n_in != 8) return PINN_E_ARCH;
   if (net->hidden != 128 && net->hidden != 256) return PINN_E_ARCH;
   if (net->n_hidden < 1 || net->n_hidden > 8) return PINN_E_ARCH;
+  if (net->precision != PINN_PREC_FP32 && net->precision != PINN_PREC_BF16) return PINN_E_ARG;
+  if (net->precision == PINN_PREC_BF16 && !net->d_packed) return PINN_E_ARG;
   return PINN_OK;
 }
 
@@ -132,10 +122,13 @@ static int num_cus() {
   return cus;
 }
 
+int launch_forward_bf16(const pinn_net_t* net, const FwdArgs& a, bool mc, void* stream);   // pinn_bf16.hip
+
 template <bool MC>
 static int launch(const pinn_net_t* net, const FwdArgs& a, void* stream) {
   const long long n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
   if (n_tiles == 0) return PINN_OK;
+  if (net->precision == PINN_PREC_BF16) return launch_forward_bf16(net, a, MC, stream);
   const int grid = (int)(n_tiles < 2 * num_cus() ? n_tiles : 2 * num_cus());
   (void)hipGetLastError();   // drop a stale error left by another HIP user of this thread
   const bool bits = a.drop.mode == PINN_DROP_BITS;

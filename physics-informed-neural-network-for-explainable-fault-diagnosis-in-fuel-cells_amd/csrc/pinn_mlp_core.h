@@ -439,6 +439,31 @@ __device__ __forceinline__ void load_block(const float* __restrict__ p, int ib, 
   for (int r = 0; r < 4; ++r) v[r] = p[(ib * 16 + r) * 16];
 }
 
+// workspace views handed from the training entry point to the fp32 / bf16 kernel launchers
+struct TrainBuffers {
+  void* stash_h;  void* stash_v1; void* stash_v2;     // [.][T16][F][16], fp32 or bf16 elements
+  void* dpre_h;   void* dpre_v1;  void* dpre_v2;
+  unsigned char* keep;
+  float* du; float* dz;
+  double* loss_part;
+  float* slabs;
+  long long t16;
+  int n_slices;
+};
+
+// kernel arguments of the forward / MC-dropout kernels (fp32 and bf16 variants)
+struct FwdArgs {
+  const float* params;
+  const float* x;
+  long long n_rows;
+  int H, nh;
+  DropDev drop;
+  int n_passes;          // MC only
+  float* o0;             // forward: u        | MC: pred_mean
+  float* o1;             // forward: logvar   | MC: a_u
+  float* o2;             //                   | MC: e_u
+};
+
 // logvar = log(softplus(z) + 1e-6), softplus with torch's threshold 20 (01:432-434)
 __device__ __forceinline__ float softplus_f32(float z) { return z > 20.0f ? z : log1pf(expf(z)); }
 

@@ -451,6 +451,8 @@ static int check_net_t(const pinn_net_t* net) {
   if (net->n_in != 8) return PINN_E_ARCH;
   if (net->hidden != 128 && net->hidden != 256) return PINN_E_ARCH;
   if (net->n_hidden < 1 || net->n_hidden > 8) return PINN_E_ARCH;
+  if (net->precision != PINN_PREC_FP32 && net->precision != PINN_PREC_BF16) return PINN_E_ARG;
+  if (net->precision == PINN_PREC_BF16 && !net->d_packed) return PINN_E_ARG;
   return PINN_OK;
 }
 
@@ -489,6 +491,11 @@ static int dispatch_wgrad(const WgradArgs& a, hipStream_t st) {
 }
 
 }  // namespace pinn
+
+namespace pinn {
+int launch_train_bf16(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y, long long n_rows,
+                      long long n_global, const DropDev& drop, const TrainBuffers& b, unsigned phases, int* grid_out, void* stream);
+}
 
 using namespace pinn;
 
@@ -546,6 +553,19 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
   const long long n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   int grid = (int)(n_tiles < 2 * cu_count() ? n_tiles : 2 * cu_count());
   if (grid > 1024) grid = 1024;
+  if (net->precision == PINN_PREC_BF16) {
+    TrainBuffers b{};
+    b.stash_h = a.stash_h; b.stash_v1 = a.stash_v1; b.stash_v2 = a.stash_v2;
+    b.dpre_h = a.dpre_h; b.dpre_v1 = a.dpre_v1; b.dpre_v2 = a.dpre_v2;
+    b.keep = a.keep; b.du = a.du; b.dz = a.dz; b.loss_part = a.loss_part;
+    b.slabs = (float*)(base + w.off_slabs); b.t16 = w.t16; b.n_slices = w.n_slices;
+    if ((rc = launch_train_bf16(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, phases, &grid, stream))) return rc;
+    if (phases & PINN_PHASE_REDUCE)
+      hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((L.total() + 255) / 256)), dim3(256), 0, st, b.slabs, w.n_slices,
+                         L.total(), a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss);
+    hipError_t eb = hipGetLastError();
+    return eb == hipSuccess ? PINN_OK : (int)eb;
+  }
   if (phases & PINN_PHASE_CHAIN) {
     const bool bits = a.drop.mode == PINN_DROP_BITS;
     if (H == 256) {

@@ -73,19 +73,33 @@ def affine_struct(sx, sy):
     return a
 
 
-def forward(lib, H, nh, fp, x, drop=None):
+_PACKED = {}
+
+
+def make_net(lib, H, nh, precision=0):
+    """pinn_net_t (+ its bf16 scratch buffer, kept alive in a module cache)."""
+    net = _lib.Net(8, H, nh, precision, None)
+    if precision:
+        nbytes = lib.pinn_packed_bytes(ctypes.byref(net))
+        assert nbytes > 0
+        buf = _PACKED.setdefault((H, nh), torch.empty(nbytes, dtype=torch.uint8, device=dev()))
+        net.d_packed = buf.data_ptr()
+    return net
+
+
+def forward(lib, H, nh, fp, x, drop=None, precision=0):
     N = x.shape[0]
     u = torch.empty(N, device=dev())
     lv = torch.empty(N, device=dev())
-    net = _lib.Net(8, H, nh)
+    net = make_net(lib, H, nh, precision)
     _lib.check(lib.pinn_mlp_forward(ctypes.byref(net), ptr(fp), ptr(x), N, ctypes.byref(drop) if drop is not None else None,
                                     ptr(u), ptr(lv), stream()), "pinn_mlp_forward")
     return u, lv
 
 
-def train_grads(lib, H, nh, fp, x, y, drop=None, n_global=None):
+def train_grads(lib, H, nh, fp, x, y, drop=None, n_global=None, precision=0):
     N = x.shape[0]
-    net = _lib.Net(8, H, nh)
+    net = make_net(lib, H, nh, precision)
     wb = lib.pinn_train_workspace_bytes(ctypes.byref(net), N)
     work = torch.empty(wb, dtype=torch.uint8, device=dev())
     grads = torch.full((fp.numel(),), float("nan"), device=dev())
