@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=100_000)
+    ap.add_argument("--no-bf16", action="store_true", help="skip the extra bf16/fp32-mixed leg")
     return ap.parse_args()
 
 
@@ -249,6 +250,51 @@ def main():
                              "e_u_mean": float(eu.mean().item())}
         for m in model.dnn.dropout_modules():
             m.p = 0.2
+
+    # ------------------------------------------------------------------ extra leg: the same step and MC launch in bf16/fp32-mixed
+    if not args.no_bf16:
+        model.dnn.set_precision("bf16")
+        model.dnn.train()
+        for _ in range(max(1, args.warmup)):
+            one_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        bf = {"dtype": "bf16 MFMA inputs, f32 accumulate/activations/loss/master weights (opt-in precision='bf16'; parity rtol 2e-2)",
+              "train_samples_per_s": n_global * args.steps / el, "ms_per_step": el / args.steps * 1e3}
+        drop_b = model.dnn.dropout_struct(7, model.row_offset)
+
+        def phase_b(ph):
+            return lambda: _lib.check(lib.pinn_mlp_train_grads_phases(
+                ctypes.byref(model.dnn._net), _ptr(flat), _ptr(xd), _ptr(yd), rows, n_global, ctypes.byref(drop_b), _ptr(model.dnn._flat_grad),
+                _ptr(loss_buf), _ptr(work), work.numel(), _stream(), ph), "phases")
+        bf["chain_ms"], bf["wgrad_ms"] = time_events(phase_b(1), reps), time_events(phase_b(2), reps)
+        if not args.no_mc:
+            T = args.mc_passes
+            for m in model.dnn.dropout_modules():
+                m.p = 0.4
+            model.mc_dropout(xd[:4096], 2); barrier()
+            t0 = time.perf_counter()
+            model.mc_dropout(xd, T, row_offset=model.row_offset)
+            barrier()
+            mc_b = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([mc_b], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                mc_b = float(t.item())
+            bf["mc_fwd_passes_per_s"] = n_global * T / mc_b
+            bf["mc_seconds"] = mc_b
+            for m in model.dnn.dropout_modules():
+                m.p = 0.2
+        out["bf16_mixed"] = bf
+        model.dnn.set_precision("fp32")
 
     if rank == 0:
         if world == 1 and not args.no_cpu:

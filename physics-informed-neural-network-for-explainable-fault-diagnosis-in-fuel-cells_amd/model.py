@@ -10,7 +10,8 @@ What is underneath is different: every numeric step is a call through the C ABI 
 include/pinn_hip.h (ctypes, raw device pointers, the current HIP stream).  torch supplies
 device memory, streams and `torch.distributed`; there is no CPU fallback.
 
-Extensions (keyword-only, all optional): `seed` (Philox dropout seed), `row_offset` /
+Extensions (keyword-only, all optional): `precision` ("fp32" exact, default; "bf16" = bf16 MFMA inputs with
+fp32 accumulation, ~3-4x faster at rtol ~2e-2), `seed` (Philox dropout seed), `row_offset` /
 `n_global` (this process holds rows [row_offset, row_offset+N) of an n_global-row series:
 data-parallel training with one all-reduce(SUM) of the flat gradient per step), and
 `train_dnn(..., batch_size=)` for minibatches.
@@ -54,7 +55,7 @@ class DNN(torch.nn.Module):
     """01:389-438.  Same module tree / state_dict keys as the reference; the 14 weight and
     bias tensors are views into ONE flat float32 device buffer that the kernels read."""
 
-    def __init__(self, p, logvar, layers, seed=0):
+    def __init__(self, p, logvar, layers, seed=0, precision="fp32"):
         super().__init__()
         self.depth = len(layers) - 1
         self.p = p
@@ -66,6 +67,8 @@ class DNN(torch.nn.Module):
         self._net = _lib.Net(self.n_in, self.hidden, self.n_hidden)
         offs, total = layout.param_offsets(self.n_in, self.hidden, self.n_hidden)
         assert self._lib.pinn_param_count(ctypes.byref(self._net)) == total
+        self._packed = None
+        self.set_precision(precision)
         self._offsets = offs
         self._flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self._flat_grad_full = torch.zeros(total + _dp.LOSS_TAIL, dtype=torch.float32, device=dev)
@@ -102,6 +105,21 @@ class DNN(torch.nn.Module):
         # when set, stochastic passes replay these masks instead of drawing Philox ones
         self._mask_bits = None
         self._mask_pass = 0
+
+    def set_precision(self, precision):
+        """"fp32" (default: exact fp32 matrix math, parity with the reference at fp32 tolerance) or "bf16"
+        (bf16 MFMA inputs, fp32 accumulate / activations / loss / master weights; ~3-4x faster, rtol ~2e-2)."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
+        if precision == "bf16":
+            probe = _lib.Net(self.n_in, self.hidden, self.n_hidden, _lib.PREC_BF16, None)
+            nbytes = self._lib.pinn_packed_bytes(ctypes.byref(probe))
+            if self._packed is None:
+                self._packed = torch.empty(nbytes, dtype=torch.uint8, device=_device())
+            self._net = _lib.Net(self.n_in, self.hidden, self.n_hidden, _lib.PREC_BF16, self._packed.data_ptr())
+        else:
+            self._net = _lib.Net(self.n_in, self.hidden, self.n_hidden, _lib.PREC_FP32, None)
 
     # -- flat buffer <-> Parameter aliasing ------------------------------------------------
     def flat_params(self):
@@ -161,7 +179,8 @@ class DNN(torch.nn.Module):
 class PhysicsInformedNN():
     """01:441-1410."""
 
-    def __init__(self, X, u, layers, x_scal, u_scal, p, logvar, *, seed=0, row_offset=0, n_global=None, process_group=None):
+    def __init__(self, X, u, layers, x_scal, u_scal, p, logvar, *, seed=0, row_offset=0, n_global=None, process_group=None,
+                 precision="fp32"):
         dev = _device()
         self._lib = _lib.load()
         self.x = X[:, 0:].clone().detach().float().to(dev).contiguous().requires_grad_(True)
@@ -177,7 +196,7 @@ class PhysicsInformedNN():
         self._lambda = torch.tensor(LAMBDA_INIT, dtype=torch.float32, device=dev)
         for i, name in enumerate(LAMBDA_NAMES):
             setattr(self, name, torch.nn.Parameter(self._lambda[i:i + 1]))
-        self.dnn = DNN(p, logvar, layers, seed=seed)
+        self.dnn = DNN(p, logvar, layers, seed=seed, precision=precision)
         # registration order and the `lambda_3` <- lambda_4 overwrite of 01:465-468 are kept for state_dict parity
         self.dnn.register_parameter("lambda_1", self.lambda_1)
         self.dnn.register_parameter("lambda_2", self.lambda_2)

@@ -42,12 +42,15 @@ def test_host_only_entry_points(lib):
         assert lib.pinn_param_count(ctypes.byref(net)) == total
         assert lib.pinn_train_workspace_bytes(ctypes.byref(net), 1000) > 0
     assert layout.param_offsets(8, 256, 3)[1] == 175362 + 6          # 175 362 parameters + two 3-float alignment pads
+    assert lib.pinn_packed_bytes(ctypes.byref(_lib.Net(8, 256, 3, _lib.PREC_BF16))) == 688128
+    assert lib.pinn_packed_bytes(ctypes.byref(_lib.Net(8, 256, 3))) == 0
+    assert lib.pinn_param_count(ctypes.byref(_lib.Net(8, 256, 3, _lib.PREC_BF16, None))) == -1      # bf16 needs its scratch buffer
     for bad in (_lib.Net(8, 96, 3), _lib.Net(7, 256, 3), _lib.Net(8, 256, 0), _lib.Net(8, 512, 3), _lib.Net(8, 256, 9)):
         assert lib.pinn_param_count(ctypes.byref(bad)) == -2
         assert lib.pinn_train_workspace_bytes(ctypes.byref(bad), 1000) == 0
     # struct layouts agree with the C side (sizes from the header's field lists)
     assert ctypes.sizeof(_lib.Affine) == 8 * 8 * 2 + 8 * 2 + 4 * 2
-    assert ctypes.sizeof(_lib.Net) == 12
+    assert ctypes.sizeof(_lib.Net) == 24          # 4 ints + 4 pad + device pointer
     assert ctypes.sizeof(_lib.Dropout) == 4 + 36 + 8 + 4 + 4 + 8 + 8   # incl. padding before row_offset
 
 

@@ -101,3 +101,29 @@ def test_train_grads_bf16(lib, H, nh, N, mode):
         # and the direction agrees closely
         cos = float((g * w).sum() / (g.norm() * w.norm() + 1e-30))
         assert cos > 0.998, (n, cos)
+
+
+def test_model_surface_bf16_end_to_end():
+    """precision="bf16" through the reference-shaped Python surface: trains, MC-samples, assembles results,
+    and stays close to the fp32 path on the same seeds."""
+    import pinn_amd
+    from pinn_amd import synth
+    ds = synth.make_dataset(3000, (300,), seed=0)
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        m = pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, 256, 256, 256, 1], ds[4], ds[5], p=0.2, logvar=True, seed=3, precision=prec)
+        m.verbose = False
+        m.train_dnn(1); l0 = m.last_loss
+        m.train_dnn(40); l1 = m.last_loss
+        assert l1 < l0
+        m.train_lambda(10, False); m.train_thermal(10)
+        arr = pinn_amd.create_comprehensive_results_array_v2(m, ds, mc_times=16, dropout=0.4)
+        assert arr.shape == (3300, 22) and np.all(np.isfinite(arr))
+        outs[prec] = (l1, arr)
+    # same seeds, same masks: the two precisions follow the same trajectory closely
+    assert abs(outs["bf16"][0] - outs["fp32"][0]) < 0.05 * abs(outs["fp32"][0]) + 0.02
+    yp32, yp16 = outs["fp32"][1][:, 9], outs["bf16"][1][:, 9]
+    assert np.abs(yp32 - yp16).max() < 0.05 * np.abs(yp32).max()
+    with pytest.raises(ValueError):
+        pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, 256, 256, 256, 1], ds[4], ds[5], p=0.2, logvar=True, precision="fp8")
