@@ -119,13 +119,14 @@ int pinn_lambda_step(int stage, const double* d_sums, long long n_global, float 
  */
 #define PINN_PREC_FP32 0  /* exact fp32 matrix math (default; parity with the reference at fp32 tolerance) */
 #define PINN_PREC_BF16 1  /* bf16 MFMA inputs, fp32 accumulate / activations / loss / master weights   */
+#define PINN_PREC_F32X6 2 /* fp32-accurate on the bf16 matrix cores: 3-way bf16 split, 6 MFMAs per product */
 
 typedef struct pinn_net {
   int n_in;       /* 8 */
   int hidden;     /* H */
   int n_hidden;   /* number of H-wide hidden layers (3 in the reference, 01:2139) */
   int precision;  /* PINN_PREC_* */
-  void* d_packed; /* PINN_PREC_BF16 only: device scratch of pinn_packed_bytes(net) bytes; every call re-packs the
+  void* d_packed; /* PINN_PREC_BF16 / _F32X6 only: device scratch of pinn_packed_bytes(net) bytes; every call re-packs the
                      bf16 weight copies from d_params into it (stateless), NULL for fp32 */
 } pinn_net_t;
 

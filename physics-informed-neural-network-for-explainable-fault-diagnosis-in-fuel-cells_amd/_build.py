@@ -19,9 +19,10 @@ SOURCES = [
     ("pinn_mlp.hip", []),
     ("pinn_train.hip", []),
     ("pinn_bf16.hip", []),
+    ("pinn_x6.hip", []),
     ("pinn_optim.hip", []),
 ]
-HEADERS = ["pinn_mlp_core.h", "pinn_bf16_core.h", os.path.join("..", "..", "include", "pinn_hip.h")]
+HEADERS = ["pinn_mlp_core.h", "pinn_bf16_core.h", "pinn_x6_core.h", os.path.join("..", "..", "include", "pinn_hip.h")]
 
 
 def _hipcc():

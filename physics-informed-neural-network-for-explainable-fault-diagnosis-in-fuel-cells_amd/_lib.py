@@ -32,7 +32,7 @@ class Affine(ctypes.Structure):
                 ("y_scale", ctypes.c_double), ("vn_scale", c_float), ("vn_min", c_float)]
 
 
-PREC_FP32, PREC_BF16 = 0, 1
+PREC_FP32, PREC_BF16, PREC_F32X6 = 0, 1, 2
 
 
 class Net(ctypes.Structure):
@@ -88,6 +88,9 @@ def load(build_if_missing=True):
     # pointers from torch are meaningless to a different runtime instance (hipErrorNoDevice).
     import torch  # noqa: F401
     path = _build.LIB
+    override = os.environ.get("PINN_HIP_LIB")      # experiments: load another build of the same ABI
+    if override:
+        path, build_if_missing = override, False
     if build_if_missing:
         try:
             path = _build.build()

@@ -451,8 +451,9 @@ static int check_net_t(const pinn_net_t* net) {
   if (net->n_in != 8) return PINN_E_ARCH;
   if (net->hidden != 128 && net->hidden != 256) return PINN_E_ARCH;
   if (net->n_hidden < 1 || net->n_hidden > 8) return PINN_E_ARCH;
-  if (net->precision != PINN_PREC_FP32 && net->precision != PINN_PREC_BF16) return PINN_E_ARG;
-  if (net->precision == PINN_PREC_BF16 && !net->d_packed) return PINN_E_ARG;
+  if (net->precision < PINN_PREC_FP32 || net->precision > PINN_PREC_F32X6) return PINN_E_ARG;
+  if (net->precision != PINN_PREC_FP32 && !net->d_packed) return PINN_E_ARG;
+  if (net->precision == PINN_PREC_F32X6) return PINN_E_ARCH;   // training in x6 precision: not implemented yet
   return PINN_OK;
 }
 

@@ -1,0 +1,169 @@
+// pinn_x6.hip -- fp32-accurate forward / MC-dropout kernels on the bf16 matrix cores
+// (pinn_net_t.precision = PINN_PREC_F32X6).  See pinn_x6_core.h.
+#include "pinn_x6_core.h"
+
+namespace pinn {
+namespace x6 {
+
+struct PackJobs6 {
+  PackJob j[18];
+  int n;
+  long long copy_stride;
+};
+
+static int cu_count_x() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+// three bf16 copies (hi, mid, lo with w = hi + mid + lo exactly) of every matrix and its transpose,
+// K permuted inside each 32-group like the bf16 path
+__global__ __launch_bounds__(256) void pack_x6_kernel(const float* __restrict__ params, __bf16* __restrict__ packed, PackJobs6 jobs) {
+  const PackJob j = jobs.j[blockIdx.y];
+  const long long n = (long long)j.rows * j.Kp;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(e / j.Kp), q = (int)(e % j.Kp);
+    const int k = (q & ~31) + pack_col(q & 31);
+    float v = 0.0f;
+    if (k < j.K) v = j.transposed ? params[j.src + (long long)k * j.src_ld + row] : params[j.src + (long long)row * j.src_ld + k];
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    packed[j.dst + e] = h;
+    packed[jobs.copy_stride + j.dst + e] = m;
+    packed[2 * jobs.copy_stride + j.dst + e] = (__bf16)r2;
+  }
+}
+
+void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st) {
+  const int H = net->hidden, nh = net->n_hidden;
+  ParamLayout L{H, nh};
+  PackLayout K{H, nh};
+  PackJobs6 jobs;
+  int n = 0;
+  auto add = [&](long long dst, long long src, int rows, int Kdim, int src_ld, int tr) {
+    jobs.j[n++] = PackJob{dst, src, rows, Kdim, round_up64(Kdim), src_ld, tr};
+  };
+  for (int l = 1; l < nh; ++l) {
+    add(K.w(l), L.w(l), H, H, H, 0);
+    add(K.wt(l), L.w(l), H, H, H, 1);
+  }
+  add(K.wv0(), L.wv0(), H / 2, H, H, 0);
+  add(K.wv0t(), L.wv0(), H, H / 2, H, 1);
+  add(K.wv1(), L.wv1(), H / 4, H / 2, H / 2, 0);
+  add(K.wv1t(), L.wv1(), H / 2, H / 4, H / 2, 1);
+  jobs.n = n;
+  jobs.copy_stride = K.total();
+  hipLaunchKernelGGL(pack_x6_kernel, dim3(64, n), dim3(256), 0, st, d_params, (__bf16*)net->d_packed, jobs);
+}
+
+template <int H, bool MC, bool kBits>
+__global__ __launch_bounds__(kThreadsX, 2) void mlp_x6_kernel(FwdArgs a, const __bf16* packed) {
+  // one LDS block, small things FIRST: a ds instruction's immediate offset is 16 bits, and every per-layer bias /
+  // head-weight address beyond 64 KB would need its own address register (hipcc hoists them all: spills)
+  constexpr int kSmallBytes = kMaxSmall * 4, kW0Bytes = 8 * kW0Stride * 4, kTabBytes = kMaxSlabs * (int)sizeof(Slab);
+  constexpr int kSlabAt = (kSmallBytes + kW0Bytes + kTabBytes + 1023) & ~1023;
+  __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * kSlabBytes];
+  float* small = reinterpret_cast<float*>(smem);
+  float* w0t = reinterpret_cast<float*>(smem + kSmallBytes);
+  Slab* tab = reinterpret_cast<Slab*>(smem + kSmallBytes + kW0Bytes);
+  char* lds_w = smem + kSlabAt;
+  ParamLayout L{a.H, a.nh};
+  PackLayout K{a.H, a.nh};
+  if (threadIdx.x == 0) build_forward_slabs(tab, K, 0);
+  {   // small parameter vectors -> LDS (all 512 threads)
+    const SmallLayout S{L.H, L.nh};
+    const int Hh = L.H, tid = threadIdx.x;
+    for (int l = 0; l < L.nh; ++l)
+      for (int i = tid; i < Hh; i += kThreadsX) small[S.b(l) + i] = a.params[L.b(l) + i];
+    for (int i = tid; i < Hh; i += kThreadsX) small[S.wp() + i] = a.params[L.wp() + i];
+    for (int i = tid; i < Hh / 2; i += kThreadsX) small[S.bv0() + i] = a.params[L.bv0() + i];
+    for (int i = tid; i < Hh / 4; i += kThreadsX) { small[S.bv1() + i] = a.params[L.bv1() + i]; small[S.wv2() + i] = a.params[L.wv2() + i]; }
+    if (tid == 0) { small[S.bp()] = a.params[L.bp()]; small[S.bv2()] = a.params[L.bv2()]; }
+    for (int e = tid; e < Hh * 8; e += kThreadsX) w0t[(e & 7) * kW0Stride + (e >> 3)] = a.params[L.w0() + e];
+    __syncthreads();
+  }
+  Pipe6 pipe;
+  pipe.packed = (const char*)packed; pipe.copy_bytes = (unsigned)(K.total() * 2); pipe.tab = tab; pipe.lds = lds_w; pipe.n = n_forward_slabs(a.H, a.nh);
+  pipe.init(threadIdx.x);
+  pipe.prime();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool late = wave >= 4;
+  const long long n_tiles = (a.n_rows + kTileRowsX - 1) / kTileRowsX;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long lrow = tile * kTileRowsX + wave * kWaveRows + (lane & 15);
+    const bool valid = lrow < a.n_rows;
+    const long long srow = valid ? lrow : a.n_rows - 1;
+    const long long grow = a.drop.row_offset + lrow;
+    const f32x4 xa = reinterpret_cast<const f32x4*>(a.x)[srow * 2];
+    const f32x4 xb = reinterpret_cast<const f32x4*>(a.x)[srow * 2 + 1];
+    RowCtx c{lane, lane >> 4, grow, srow, a.n_rows, 0u, a.drop.mode};
+    if (!MC) {
+      float u, z;
+      forward_pass_x6<H, kBits>(w0t, small, L, pipe, a.drop, c, xa, xb, late, u, z);
+      if (valid && lane < 16) {
+        a.o0[lrow] = u;
+        a.o1[lrow] = logf(softplus_f32(z) + 1e-6f);
+      }
+    } else {
+      float u_eval = 0.f, s1 = 0.f, s2 = 0.f, sl = 0.f;
+#pragma unroll 1
+      for (int t = -1; t < a.n_passes; ++t) {
+        c.mode = (t < 0) ? PINN_DROP_NONE : a.drop.mode;
+        c.pass = (unsigned)(t < 0 ? 0 : t);
+        float u, z;
+        forward_pass_x6<H, kBits>(w0t, small, L, pipe, a.drop, c, xa, xb, late, u, z);
+        if (t < 0) {
+          u_eval = u;
+        } else {
+          const float du = u - u_eval;
+          s1 += du;
+          s2 = fmaf(du, du, s2);
+          sl += logf(softplus_f32(z) + 1e-6f);
+        }
+      }
+      if (valid && lane < 16) {
+        const float inv_t = 1.0f / (float)a.n_passes;
+        const float m = s1 * inv_t;
+        const float var = fmaxf(s2 * inv_t - m * m, 0.0f);
+        a.o0[lrow] = u_eval;
+        a.o1[lrow] = expf(0.5f * (sl * inv_t));
+        a.o2[lrow] = sqrtf(var);
+      }
+    }
+  }
+}
+
+}  // namespace x6
+
+int launch_forward_x6(const pinn_net_t* net, const FwdArgs& a, bool mc, void* stream) {
+  using namespace x6;
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipGetLastError();
+  launch_pack_x6(net, a.params, st);
+  const long long n_tiles = (a.n_rows + kTileRowsX - 1) / kTileRowsX;
+  const int grid = (int)(n_tiles < cu_count_x() ? n_tiles : cu_count_x());
+  const __bf16* packed = (const __bf16*)net->d_packed;
+  const bool bits = a.drop.mode == PINN_DROP_BITS;
+#define PINN_LAUNCH_X(HH, MCC, BB) hipLaunchKernelGGL((mlp_x6_kernel<HH, MCC, BB>), dim3(grid), dim3(kThreadsX), 0, st, a, packed)
+  if (net->hidden == 256) {
+    if (mc) { if (bits) PINN_LAUNCH_X(256, true, true); else PINN_LAUNCH_X(256, true, false); }
+    else    { if (bits) PINN_LAUNCH_X(256, false, true); else PINN_LAUNCH_X(256, false, false); }
+  } else {
+    if (mc) { if (bits) PINN_LAUNCH_X(128, true, true); else PINN_LAUNCH_X(128, true, false); }
+    else    { if (bits) PINN_LAUNCH_X(128, false, true); else PINN_LAUNCH_X(128, false, false); }
+  }
+#undef PINN_LAUNCH_X
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PINN_OK : (int)e;
+}
+
+}  // namespace pinn

@@ -82,7 +82,7 @@ def make_net(lib, H, nh, precision=0):
     if precision:
         nbytes = lib.pinn_packed_bytes(ctypes.byref(net))
         assert nbytes > 0
-        buf = _PACKED.setdefault((H, nh), torch.empty(nbytes, dtype=torch.uint8, device=dev()))
+        buf = _PACKED.setdefault((H, nh, precision), torch.empty(nbytes, dtype=torch.uint8, device=dev()))
         net.d_packed = buf.data_ptr()
     return net
 

@@ -1,0 +1,80 @@
+"""GPU parity of the fp32-accurate matrix-core kernels (pinn_net_t.precision = PINN_PREC_F32X6):
+3-way bf16 split of both operands, six bf16 MFMAs per product, fp32 accumulation.  The bar is the
+SAME fp32 tolerance as the exact-fp32 kernels (rtol = atol = 1e-5 against the fp32 oracle)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import pinn_oracle as O
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pinn_amd import _lib
+    return _lib.load()
+
+
+@pytest.mark.parametrize("H,nh,N,mode", [(256, 3, 1000, 0), (256, 3, 777, 1), (128, 3, 333, 1), (128, 1, 64, 1), (256, 5, 130, 1),
+                                         (256, 3, 1, 0), (128, 2, 4097, 0)])
+def test_forward_x6(lib, H, nh, N, mode):
+    import hip_helpers as hh
+    from pinn_amd import synth
+    P = O.init_params([8] + [H] * nh + [1], seed=H + nh)
+    x = synth.make_dataset(max(N, 2), (), seed=N)[0][:N].contiguous()
+    fp, xd = hh.flat_params(P, H, nh).to(hh.dev()), x.to(hh.dev())
+    pl = [0.2] * (nh + 1)
+    seed, stream, row0 = 424242, 9, 1000
+    drop = hh.dropout_struct(mode, pl, seed=seed, stream_id=stream, row_offset=row0)
+    u, lv = hh.forward(lib, H, nh, fp, xd, drop, precision=2)
+    masks = O.philox_masks_for_net(seed, stream, row0, N, H, nh, pl) if mode else None
+    with torch.no_grad():
+        uf, lvf = O.mlp_forward(P, x, pl, masks)
+    np.testing.assert_allclose(u.cpu().numpy(), uf.numpy().reshape(-1), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lv.cpu().numpy(), lvf.numpy().reshape(-1), rtol=1e-5, atol=1e-5)
+    # and as close to the exact-fp32 kernels as those are to the oracle
+    u0, lv0 = hh.forward(lib, H, nh, fp, xd, drop, precision=0)
+    np.testing.assert_allclose(u.cpu().numpy(), u0.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lv.cpu().numpy(), lv0.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_forward_x6_injected_masks(lib):
+    import hip_helpers as hh
+    from pinn_amd import synth
+    H, nh, N = 256, 3, 500
+    P = O.init_params([8, H, H, H, 1], seed=5)
+    x = synth.make_dataset(N, (), seed=6)[0]
+    g = torch.Generator().manual_seed(3)
+    widths = [H] * nh + [H // 2]
+    masks = [(torch.rand(N, w, generator=g) >= 0.2).numpy() for w in widths]
+    bits = hh.pack_mask_bits([masks]).to(hh.dev())
+    drop = hh.dropout_struct(2, [0.2] * 4, bits=bits)
+    fp, xd = hh.flat_params(P, H, nh).to(hh.dev()), x.to(hh.dev())
+    u, lv = hh.forward(lib, H, nh, fp, xd, drop, precision=2)
+    with torch.no_grad():
+        uf, lvf = O.mlp_forward(P, x, [0.2] * 4, [torch.from_numpy(m) for m in masks])
+    np.testing.assert_allclose(u.cpu().numpy(), uf.numpy().reshape(-1), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lv.cpu().numpy(), lvf.numpy().reshape(-1), rtol=1e-5, atol=1e-5)
+
+
+def test_mc_dropout_x6(lib):
+    import hip_helpers as hh
+    from pinn_amd import _lib, synth
+    H, nh, N, T, p = 256, 3, 300, 16, 0.4
+    P = O.init_params([8, H, H, H, 1], seed=1)
+    x = synth.make_dataset(N, (), seed=2)[0]
+    out = torch.empty(3, N, device=hh.dev())
+    net = hh.make_net(lib, H, nh, 2)
+    d = hh.dropout_struct(1, [p] * 4, seed=99, stream_id=1000, row_offset=0)
+    fp, xd = hh.flat_params(P, H, nh).to(hh.dev()), x.to(hh.dev())
+    _lib.check(lib.pinn_mc_dropout(ctypes.byref(net), hh.ptr(fp), hh.ptr(xd), N, ctypes.byref(d), T, hh.ptr(out[0]), hh.ptr(out[1]),
+                                   hh.ptr(out[2]), hh.stream()), "mc")
+    o = out.cpu().numpy()
+    mf = lambda t: O.philox_masks_for_net(99, 1000 + t, 0, N, H, nh, [p] * 4)
+    pm, au, eu = O.mc_dropout(P, x, p, T, mf)
+    np.testing.assert_allclose(o[0], np.asarray(pm).reshape(-1), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(o[1], np.asarray(au).reshape(-1), rtol=1e-4)
+    np.testing.assert_allclose(o[2], np.asarray(eu).reshape(-1), rtol=1e-3, atol=1e-5)
