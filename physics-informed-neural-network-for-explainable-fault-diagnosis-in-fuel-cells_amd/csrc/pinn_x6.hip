@@ -23,13 +23,13 @@ static int cu_count_x() {
 }
 
 // three bf16 copies (hi, mid, lo with w = hi + mid + lo exactly) of every matrix and its transpose,
-// K permuted inside each 32-group like the bf16 path
+// K permuted inside each 32-group (pack_col_x6)
 __global__ __launch_bounds__(256) void pack_x6_kernel(const float* __restrict__ params, __bf16* __restrict__ packed, PackJobs6 jobs) {
   const PackJob j = jobs.j[blockIdx.y];
   const long long n = (long long)j.rows * j.Kp;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
     const int row = (int)(e / j.Kp), q = (int)(e % j.Kp);
-    const int k = (q & ~31) + pack_col(q & 31);
+    const int k = (q & ~31) + pack_col_x6(q & 31);
     float v = 0.0f;
     if (k < j.K) v = j.transposed ? params[j.src + (long long)k * j.src_ld + row] : params[j.src + (long long)row * j.src_ld + k];
     const __bf16 h = (__bf16)v;
@@ -68,16 +68,14 @@ template <int H, bool MC, bool kBits>
 __global__ __launch_bounds__(kThreadsX, 2) void mlp_x6_kernel(FwdArgs a, const __bf16* packed) {
   // one LDS block, small things FIRST: a ds instruction's immediate offset is 16 bits, and every per-layer bias /
   // head-weight address beyond 64 KB would need its own address register (hipcc hoists them all: spills)
-  constexpr int kSmallBytes = kMaxSmall * 4, kW0Bytes = 8 * kW0Stride * 4, kTabBytes = kMaxSlabs * (int)sizeof(Slab);
-  constexpr int kSlabAt = (kSmallBytes + kW0Bytes + kTabBytes + 1023) & ~1023;
+  constexpr int kSmallBytes = kMaxSmall * 4, kW0Bytes = 8 * kW0Stride * 4;
+  constexpr int kSlabAt = (kSmallBytes + kW0Bytes + 1023) & ~1023;
   __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * kSlabBytes];
   float* small = reinterpret_cast<float*>(smem);
   float* w0t = reinterpret_cast<float*>(smem + kSmallBytes);
-  Slab* tab = reinterpret_cast<Slab*>(smem + kSmallBytes + kW0Bytes);
   char* lds_w = smem + kSlabAt;
   ParamLayout L{a.H, a.nh};
   PackLayout K{a.H, a.nh};
-  if (threadIdx.x == 0) build_forward_slabs(tab, K, 0);
   {   // small parameter vectors -> LDS (all 512 threads)
     const SmallLayout S{L.H, L.nh};
     const int Hh = L.H, tid = threadIdx.x;
@@ -91,12 +89,15 @@ __global__ __launch_bounds__(kThreadsX, 2) void mlp_x6_kernel(FwdArgs a, const _
     __syncthreads();
   }
   Pipe6 pipe;
-  pipe.packed = (const char*)packed; pipe.copy_bytes = (unsigned)(K.total() * 2); pipe.tab = tab; pipe.lds = lds_w; pipe.n = n_forward_slabs(a.H, a.nh);
+  pipe.packed = (const char*)packed; pipe.copy_bytes = (unsigned)(K.total() * 2); pipe.lds = lds_w;
   pipe.init(threadIdx.x);
-  pipe.prime();
+  pipe.prime<clog2(H)>(first_mat<H>(K));
+#ifdef PINN_X6_STAMP
+  for (int k = 0; k < 4; ++k) pipe.seg[k] = 0;
+  pipe.last = stamp();
+#endif
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool late = wave >= 4;
   const long long n_tiles = (a.n_rows + kTileRowsX - 1) / kTileRowsX;
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long lrow = tile * kTileRowsX + wave * kWaveRows + (lane & 15);
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(kThreadsX, 2) void mlp_x6_kernel(FwdArgs a, const _
     RowCtx c{lane, lane >> 4, grow, srow, a.n_rows, 0u, a.drop.mode};
     if (!MC) {
       float u, z;
-      forward_pass_x6<H, kBits>(w0t, small, L, pipe, a.drop, c, xa, xb, late, u, z);
+      PINN_STAMP(pipe, 3);
+      forward_pass_x6<H, kBits>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z);
       if (valid && lane < 16) {
         a.o0[lrow] = u;
         a.o1[lrow] = logf(softplus_f32(z) + 1e-6f);
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(kThreadsX, 2) void mlp_x6_kernel(FwdArgs a, const _
         c.mode = (t < 0) ? PINN_DROP_NONE : a.drop.mode;
         c.pass = (unsigned)(t < 0 ? 0 : t);
         float u, z;
-        forward_pass_x6<H, kBits>(w0t, small, L, pipe, a.drop, c, xa, xb, late, u, z);
+        PINN_STAMP(pipe, 3);
+        forward_pass_x6<H, kBits>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z);
         if (t < 0) {
           u_eval = u;
         } else {
@@ -140,6 +143,10 @@ __global__ __launch_bounds__(kThreadsX, 2) void mlp_x6_kernel(FwdArgs a, const _
       }
     }
   }
+#ifdef PINN_X6_STAMP
+  if (blockIdx.x == 0 && lane == 0)
+    for (int k = 0; k < 4; ++k) g_x6_stamps[wave * 4 + k] = pipe.seg[k];
+#endif
 }
 
 }  // namespace x6
@@ -167,3 +174,9 @@ int launch_forward_x6(const pinn_net_t* net, const FwdArgs& a, bool mc, void* st
 }
 
 }  // namespace pinn
+
+#ifdef PINN_X6_STAMP
+extern "C" int pinn_x6_debug_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pinn::x6::g_x6_stamps), sizeof(unsigned long long) * 32);
+}
+#endif

@@ -13,29 +13,46 @@
 // Structure: one 512-thread workgroup per CU = 8 waves x 16 rows (two waves per SIMD, <= 256
 // registers each).  Weights are pre-split and pre-permuted into three bf16 copies (hi, mid, lo;
 // pack kernel, once per call); one LDS slab = one 32-feature K-group of a layer for all output rows
-// = 3 x [rows][64 B], two slabs in flight (<= 96 KB), one barrier per slab.  Activation is LAZY: while
-// slab kb multiplies, the raw accumulators of K-group kb+1 are turned into their three bf16
-// fragments (bias is already in the accumulator; tanh, dropout, split).  Waves 4-7 run "MFMAs, then
-// prepare" and waves 0-3 "prepare, then MFMAs", so on every SIMD one wave feeds the matrix core while
-// its partner uses the VALU, although both follow the same barrier-synchronised slab sequence.
+// = 3 x [rows][64 B], two slabs in flight (<= 96 KB), one barrier per slab.  Activation is LAZY and
+// INTERLEAVED: while slab g multiplies, the raw accumulators of K-group g + 1 are turned into their
+// three bf16 fragments (bias is already in the accumulator; Philox, tanh, dropout, split) in six
+// micro-steps placed between the slab's MFMA groups, together with the LDS-DMA pieces of the next
+// slab.  The matrix core arbitrates strictly oldest-wave-first, so phase-staggering the two waves of
+// a SIMD ("one multiplies while the other prepares") serialises instead; with fine interleaving each
+// wave's VALU chunk simply runs under the other wave's (and its own) MFMAs.
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "pinn_bf16_core.h"
 
 namespace pinn {
 namespace x6 {
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}).  The slab code
+// indexes register arrays and vector lanes with these; a "runtime" index that the optimiser fails to fold sends
+// the whole array to scratch.
+template <int I>
+using IC = std::integral_constant<int, I>;
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(IC<I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 constexpr int kThreadsX = 512;       // 8 waves
 constexpr int kTileRowsX = 128;      // rows per workgroup tile
 constexpr int kSlabBytes = 49152;    // 3 copies x 256 rows x 64 B
-constexpr int kMaxSlabs = 200;
 
-// packed buffer: three copies (hi, mid, lo) of the bf16 layout of pinn_bf16_core.h (PackLayout), back to back
-struct Slab {
-  unsigned off;            // bf16-element offset of (row 0, this 32-group) inside one copy
-  unsigned char kp_log;    // log2 of the row stride of the packed matrix (bf16 elements)
-  unsigned char nrb_log;   // log2 of (output rows of the layer / 16): 16-row blocks per copy
-  unsigned short pad;
+// packed buffer: three copies (hi, mid, lo) of the bf16 layout of pinn_bf16_core.h (PackLayout), back to back.
+// One matrix of it, as the weight stream sees it (wave-uniform; the row stride is a template argument of the users):
+struct Mat {
+  unsigned off;      // bf16-element offset of (row 0, column 0) inside one copy
+  int nrb_log;       // log2 of (output rows / 16): 16-row blocks per copy; a slab has 3 << nrb_log 1-KB pieces
 };
+constexpr int clog2(int v) { return v <= 1 ? 0 : 1 + clog2(v >> 1); }
 
 // swizzle of the four 16-B kq chunks of a 64-B row so that ds_read_b128 is conflict-free for the hardware's
 // lane groups {0-3,12-15,20-27} ... : chunk' = kq ^ g[(row >> 2) & 3], g = {0, 2, 3, 1}
@@ -44,16 +61,38 @@ __device__ __forceinline__ int swz(int row) { return (0x78 >> (2 * ((row >> 2) &
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// Weight stream, global (L2) -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass,
-// and nothing for the compute phase's waits to trip over).  One wave-instruction moves one 1-KB piece = 16 rows x
-// 64 B of one copy; the LDS image of a piece is lane-linear, so the kq-chunk swizzle is applied to the SOURCE
-// address: LDS chunk c of row r holds kq = c ^ swz(r) (an involution, the reader applies the same one).
+#ifdef PINN_X6_STAMP
+// diagnostic build only: per-wave cycle sums of the segments of a slab step (first phase, second phase,
+// wait + barrier), read back with pinn_x6_debug_read()
+__device__ unsigned long long g_x6_stamps[8 * 4];
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define PINN_STAMP(pipe, k) do { const unsigned long long t_ = stamp(); (pipe).seg[k] += t_ - (pipe).last; (pipe).last = t_; } while (0)
+#else
+#define PINN_STAMP(pipe, k) do { } while (0)
+#endif
+
+// Weight stream, global (L2) -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass).
+// One slab = one 32-feature K-group of a matrix for all its output rows = 3 copies x [rows][64 B]; two slabs in LDS:
+// while slab k is multiplied, slab k + 1 streams into the other buffer.  One wave-instruction moves one 1-KB piece
+// = 16 rows x 64 B of one copy; wave w owns pieces w, w + 8, ... (<= 6).  The LDS image of a piece is lane-linear,
+// so the kq-chunk swizzle is applied to the SOURCE address: LDS chunk c of row r holds kq = c ^ swz(r) (an
+// involution, the reader applies the same one).  A CU's vector-memory path takes 64 B/clk: issued as one burst
+// after the barrier, the 48 pieces of a slab stall all eight waves at issue for ~1000 cycles, so each wave issues
+// its pieces one at a time between the MFMAs of its multiply phase (slab_mfma), where the issue slot is free.
 struct Pipe6 {
+#ifdef PINN_X6_STAMP
+  unsigned long long seg[4], last;
+#endif
   const char* packed;        // copy 0 (bytes); copies 1, 2 follow at +copy_bytes
   unsigned copy_bytes;
-  const Slab* tab;           // in LDS
   char* lds;                 // 2 x kSlabBytes
-  int n, ci, wave;
+  int par, wave;             // buffer holding the current slab; wave index (uniform)
   unsigned lane_row, lane_kq8;   // (lane >> 2), 16 B * ((lane & 3) ^ swz(lane >> 2))
 
   __device__ __forceinline__ void init(int tid) {
@@ -62,118 +101,139 @@ struct Pipe6 {
     lane_row = lane >> 2;
     lane_kq8 = (unsigned)(((lane & 3) ^ swz(lane >> 2)) << 4);
   }
-  __device__ __forceinline__ void issue(int idx_slab, int buf) {
-    const unsigned off = __builtin_amdgcn_readfirstlane(tab[idx_slab].off);
-    const int kp_log = __builtin_amdgcn_readfirstlane(tab[idx_slab].kp_log);
-    const int nrb_log = __builtin_amdgcn_readfirstlane(tab[idx_slab].nrb_log);
-    const unsigned voff = ((lane_row << kp_log) << 1) + lane_kq8;          // bytes, per lane
-    const int n_pieces = 3 << nrb_log;
+  // this wave's j-th piece of K-group g of matrix m (row stride 2^KP_LOG) into buffer buf.  Branch-free: a wave whose
+  // j-th piece does not exist (small matrices) fetches piece p - n again instead -- same bytes to the same place.
+  template <int KP_LOG>
+  __device__ __forceinline__ void piece(const Mat& m, int g, int j, int buf) {
+    int p = wave + 8 * j;
+    const int n = 3 << m.nrb_log;
+    p = p < n ? p : p - n;
+    asm volatile("" : "+s"(p));   // or hipcc precomputes every piece's 64-bit address outside the row loop (spills)
+    const unsigned voff = ((lane_row << KP_LOG) << 1) + lane_kq8;          // bytes, per lane
+    const int copy = p >> m.nrb_log, rb = p & ((1 << m.nrb_log) - 1);
+    const unsigned long long goff = (unsigned long long)copy * copy_bytes + 2ull * (m.off + 32u * (unsigned)g + ((unsigned)(rb * 16) << KP_LOG));
+    char* dst = lds + buf * kSlabBytes + copy * (kSlabBytes / 3) + rb * 1024;
+    __builtin_amdgcn_global_load_lds((gptr_t)(packed + goff + voff), (lptr_t)dst, 16, 0, 0);
+  }
+  // slab 0 of the sequence
+  template <int KP_LOG>
+  __device__ __forceinline__ void prime(const Mat& first) {
+    par = 0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int piece = wave + 8 * j;
-      if (piece < n_pieces) {                                              // wave-uniform
-        const int copy = piece >> nrb_log, rb = piece & ((1 << nrb_log) - 1);
-        const unsigned long long goff = (unsigned long long)copy * copy_bytes + 2ull * (off + ((unsigned)(rb * 16) << kp_log));
-        char* dst = lds + buf * kSlabBytes + copy * (kSlabBytes / 3) + rb * 1024;
-        __builtin_amdgcn_global_load_lds((gptr_t)(packed + goff + voff), (lptr_t)dst, 16, 0, 0);
-      }
-    }
-  }
-  __device__ __forceinline__ void prime() {
-    ci = 0;
-    issue(0, 0);
+    for (int j = 0; j < 6; ++j)
+      if (8 * j < (3 << first.nrb_log)) piece<KP_LOG>(first, 0, j, 0);
     __syncthreads();           // (drains the DMA: vmcnt(0) + barrier)
-    issue(n > 1 ? 1 : 0, 1);
   }
-  __device__ __forceinline__ const char* cur() const { return lds + (ci & 1) * kSlabBytes; }
-  // end of a slab step: the DMA of slab ci + 1 has had the whole step to land; after the barrier every wave is done
-  // reading slab ci, whose buffer the DMA of slab ci + 2 may overwrite
+  __device__ __forceinline__ const char* cur() const { return lds + par * kSlabBytes; }
+  // end of a slab step: the barrier's vmcnt(0) retires this wave's pieces of the next slab; past it every wave is
+  // done reading the current slab and the next one is complete
   __device__ __forceinline__ void advance() {
     __syncthreads();
-    ++ci;
-    issue((ci + 1) % n, (ci + 1) & 1);
+    par ^= 1;
   }
 };
-
-// slab cycle of one forward pass: every 32-group of every matrix, in consumption order
-__device__ __forceinline__ int add_groups(Slab* tab, int k, long long off_bf16, int rows, int K, int Kp) {
-  const unsigned char kp_log = (unsigned char)(31 - __builtin_clz((unsigned)Kp)), nrb_log = (unsigned char)(31 - __builtin_clz((unsigned)(rows / 16)));
-  for (int g = 0; g < K / 32; ++g) tab[k++] = Slab{(unsigned)(off_bf16 + g * 32), kp_log, nrb_log, 0};
-  return k;
-}
-__device__ __forceinline__ int build_forward_slabs(Slab* tab, const PackLayout& L, int at) {
-  int k = at;
-  const int H = L.H;
-  for (int l = 1; l < L.nh; ++l) k = add_groups(tab, k, L.w(l), H, H, H);
-  k = add_groups(tab, k, L.wv0(), H / 2, H, H);
-  k = add_groups(tab, k, L.wv1(), H / 4, H / 2, round_up64(H / 2));
-  return k;
-}
-__device__ __forceinline__ int build_backward_slabs(Slab* tab, const PackLayout& L, int at) {
-  int k = at;
-  const int H = L.H;
-  k = add_groups(tab, k, L.wv1t(), H / 2, H / 4, round_up64(H / 4));
-  k = add_groups(tab, k, L.wv0t(), H, H / 2, round_up64(H / 2));
-  for (int l = L.nh - 1; l >= 1; --l) k = add_groups(tab, k, L.wt(l), H, H, H);
-  return k;
-}
-__host__ __device__ inline int n_forward_slabs(int H, int nh) { return (nh - 1) * (H / 32) + H / 32 + H / 64; }
-__host__ __device__ inline int n_backward_slabs(int H, int nh) { return H / 128 + H / 64 + (nh - 1) * (H / 32); }
 
 // three bf16 fragments of the 8 fp32 values a lane holds in one 32-group: v = hi + mid + lo (exact)
+// K order inside a 32-group for the x6 kernels: B-fragment element jj = 2 r + b of lane group kq is feature
+// 16 b + 4 kq + r, i.e. the lane's register r of block 2g + b.  One micro-step (register r of both blocks) then
+// produces one whole dword of each fragment (v_cvt_pk_bf16_f32), never half of one.
+__host__ __device__ inline int pack_col_x6(int q) { return 16 * (q & 1) + 4 * (q >> 3) + ((q & 7) >> 1); }
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// three bf16 fragments of the 8 fp32 values a lane holds in one 32-group: v = hi + mid + lo (exact); dword r of each
+// = (register r of block 0, register r of block 1)
 struct Frag3 {
-  bf16x8 hi, mid, lo;
+  u32x4 hi, mid, lo;
 };
+template <int R>
+__device__ __forceinline__ void split_pair(float x0, float x1, Frag3& f) {
+  const bf16x2 h = {(__bf16)x0, (__bf16)x1};
+  const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
+  const bf16x2 m = {(__bf16)r0, (__bf16)r1};
+  const float q0 = r0 - (float)m[0], q1 = r1 - (float)m[1];
+  const bf16x2 l = {(__bf16)q0, (__bf16)q1};
+  f.hi[R] = __builtin_bit_cast(unsigned, h);
+  f.mid[R] = __builtin_bit_cast(unsigned, m);
+  f.lo[R] = __builtin_bit_cast(unsigned, l);
+}
 __device__ __forceinline__ Frag3 split3(const f32x4& v0, const f32x4& v1) {
   Frag3 f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float v = j < 4 ? v0[j] : v1[j - 4];
-    const __bf16 h = (__bf16)v;
-    const float r1 = v - (float)h;
-    const __bf16 m = (__bf16)r1;
-    const float r2 = r1 - (float)m;
-    f.hi[j] = h; f.mid[j] = m; f.lo[j] = (__bf16)r2;
-  }
+  split_pair<0>(v0[0], v1[0], f);
+  split_pair<1>(v0[1], v1[1], f);
+  split_pair<2>(v0[2], v1[2], f);
+  split_pair<3>(v0[3], v1[3], f);
   return f;
 }
 
-// the 6 x NTOUT MFMAs of one slab: acc[mt] += A_mt (hi, mid, lo) x B (hi, mid, lo), terms of order >= 2^-24 dropped.
-// The three A fragments of tile mt + 1 are requested before the MFMAs of tile mt are issued (hipcc reuses one
-// register set and waits lgkmcnt(0) per tile otherwise: the whole LDS latency exposed 16 times per slab).
 struct AFrag3 {
   bf16x8 h, m, l;
 };
-__device__ __forceinline__ AFrag3 load_a3(const char* base, int mt) {
+// A-fragment reads and their waits are written by hand: with an LDS-DMA between the reads hipcc waits lgkmcnt(0)
+// before every tile's MFMAs -- for the reads it has just issued too -- and the LDS latency (200+ cycles under load)
+// is exposed once per 6 MFMAs (96 cycles).  LDS returns in order, so "at most 3 outstanding" retires the older tile.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_b128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return __builtin_bit_cast(bf16x8, v);
+}
+template <int MT>
+__device__ __forceinline__ void load_a3(AFrag3& a, unsigned addr) {
   constexpr int kCopy = kSlabBytes / 3;
-  AFrag3 a;
-  a.h = *reinterpret_cast<const bf16x8*>(base + mt * 1024);
-  a.m = *reinterpret_cast<const bf16x8*>(base + kCopy + mt * 1024);
-  a.l = *reinterpret_cast<const bf16x8*>(base + 2 * kCopy + mt * 1024);
-  return a;
+  a.h = lds_read_b128<MT * 1024>(addr);
+  a.m = lds_read_b128<kCopy + MT * 1024>(addr);
+  a.l = lds_read_b128<2 * kCopy + MT * 1024>(addr);
+}
+template <int N>
+__device__ __forceinline__ void wait_a3(AFrag3& a) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a.h), "+v"(a.m), "+v"(a.l) : "n"(N));
 }
 __device__ __forceinline__ void mfma6(f32x4& acc, const AFrag3& a, const Frag3& b) {
   f32x4 c = acc;
-  c = PINN_MFMA_BF16(a.l, b.hi, c);
-  c = PINN_MFMA_BF16(a.h, b.lo, c);
-  c = PINN_MFMA_BF16(a.m, b.mid, c);
-  c = PINN_MFMA_BF16(a.m, b.hi, c);
-  c = PINN_MFMA_BF16(a.h, b.mid, c);
-  c = PINN_MFMA_BF16(a.h, b.hi, c);
+  const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi), bm = __builtin_bit_cast(bf16x8, b.mid), bl = __builtin_bit_cast(bf16x8, b.lo);
+  c = PINN_MFMA_BF16(a.l, bh, c);
+  c = PINN_MFMA_BF16(a.h, bl, c);
+  c = PINN_MFMA_BF16(a.m, bm, c);
+  c = PINN_MFMA_BF16(a.m, bh, c);
+  c = PINN_MFMA_BF16(a.h, bm, c);
+  c = PINN_MFMA_BF16(a.h, bh, c);
   acc = c;
 }
-template <int NTOUT>
-__device__ __forceinline__ void slab_mfma(f32x4 (&acc)[NTOUT], const Frag3& b, const char* slab, int lane) {
+// One tile pair.  vchunk(IC<c>): VALU chunk c (one per tile) of the next group's preparation; dma(IC<slot>): this
+// wave's LDS-DMA piece(s) of the next slab.  Order pinned: MFMAs of a tile, reads of the tile after next, chunk.
+// (Measured alternatives, all slower or equal: chunk free to mix with the MFMAs; sched_group_barrier 1 MFMA : 5 VALU;
+// waves 4-7 running each chunk before instead of after its tile's MFMAs; whole-phase staggering of the two waves.)
+template <int MT, int NTOUT, typename V, typename D>
+__device__ __forceinline__ void slab_pair(f32x4 (&acc)[NTOUT], const Frag3& b, unsigned addr, AFrag3& a0, AFrag3& a1, V&& vchunk, D&& dma) {
+  wait_a3<3>(a0);                                   // a1 (issued after a0) may still be in flight
+  mfma6(acc[MT], a0, b);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (MT + 2 < NTOUT) load_a3<MT + 2>(a0, addr);
+  dma(IC<MT / 2>{});
+  vchunk(IC<MT>{});
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (MT + 2 < NTOUT) wait_a3<3>(a1); else wait_a3<0>(a1);
+  mfma6(acc[MT + 1], a1, b);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (MT + 3 < NTOUT) load_a3<MT + 3>(a1, addr);
+  vchunk(IC<MT + 1>{});
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (MT + 2 < NTOUT) slab_pair<MT + 2, NTOUT>(acc, b, addr, a0, a1, vchunk, dma);
+}
+// the 6 x NTOUT MFMAs of one slab: acc[mt] += A_mt (hi, mid, lo) x B (hi, mid, lo), terms of order >= 2^-24 dropped.
+// Program order is pinned (sched_barrier); two tiles of A fragments in flight.
+template <int NTOUT, typename V, typename D>
+__device__ __forceinline__ void slab_mfma(f32x4 (&acc)[NTOUT], const Frag3& b, const char* slab, int lane, V&& vchunk, D&& dma) {
   const int kq = lane >> 4, i = lane & 15;
   const char* base = slab + i * 64 + ((kq ^ swz(i)) << 4);      // rows mt*16 + i: (row >> 2) & 3 == (i >> 2) & 3
-  AFrag3 a0 = load_a3(base, 0), a1 = a0;
-#pragma unroll
-  for (int mt = 0; mt < NTOUT; mt += 2) {
-    a1 = load_a3(base, mt + 1);
-    mfma6(acc[mt], a0, b);
-    if (mt + 2 < NTOUT) a0 = load_a3(base, mt + 2);
-    mfma6(acc[mt + 1], a1, b);
-  }
+  const unsigned addr = (unsigned)(unsigned long long)(lptr_t)base;
+  AFrag3 a0, a1;
+  __builtin_amdgcn_sched_barrier(0);
+  load_a3<0>(a0, addr);
+  load_a3<1>(a1, addr);
+  __builtin_amdgcn_sched_barrier(0);
+  slab_pair<0, NTOUT>(acc, b, addr, a0, a1, vchunk, dma);
 }
 
 // input layer from LDS: acc = b0 + W0 x^T in exact fp32 (K = 8); w0t is [8][kW0Stride] (k-major, padded: conflict-free)
@@ -195,85 +255,186 @@ __device__ __forceinline__ void layer_input_lds(f32x4 (&acc)[NTOUT], const float
   }
 }
 
-// One layer: NG K-groups.  prep(g) returns the Frag3 of group g (lazy activation of the previous layer's raw
-// output, or the backward chain's dpre).  Early waves (0-3) run "prepare g, multiply g", late waves (4-7) "multiply g,
-// prepare g + 1": on every SIMD one wave feeds the matrix core while its partner is on the VALU, and neither holds
-// more than one fragment set.
-template <int NG, int NTOUT, typename F>
-__device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], Pipe6& pipe, int lane, bool late, F&& prep) {
-  Frag3 cur;
-  if (late) cur = prep(0);
+// ---------------------------------------------------------------------------------------
+// preparing a 32-feature K-group (two 16-feature blocks v0, v1 of raw pre-activations -> activated in
+// place -> Frag3) in six micro-steps: 0, 1 = Philox4x32-10 (five rounds each) and the 8 keep bits;
+// 2 .. 5 = register r = k - 2 of both blocks: tanh, dropout, 3-way split (and the predict head's dot).
+// ---------------------------------------------------------------------------------------
+struct Prep {
+  unsigned c0, c1, c2, c3, k0, k1;   // Philox state between micro-steps 0 and 1
+  unsigned keep;
+  Frag3 out;
+};
+__device__ __forceinline__ void philox_rounds5(Prep& s) {
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    if (late) {
-      slab_mfma<NTOUT>(acc, cur, pipe.cur(), lane);
-      if (g + 1 < NG) cur = prep(g + 1);
+  for (int r = 0; r < 5; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * s.c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * s.c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ s.c1 ^ s.k0;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ s.c3 ^ s.k1;
+    s.c1 = (unsigned)p1; s.c3 = (unsigned)p0; s.c0 = n0; s.c2 = n2;
+    s.k0 += 0x9E3779B9u; s.k1 += 0xBB67AE85u;
+  }
+}
+// wp32: the predict head's 32 weights of this group (LDS) when kDot; the dot is accumulated only if dot_on
+template <bool kBits, bool kDot, int k>
+__device__ __forceinline__ void prep_micro(Prep& s, f32x4& v0, f32x4& v1, const DropDev& d, const RowCtx& c, const LayerDrop ld,
+                                           int layer, int fp, const float* wp32, float& up, bool dot_on) {
+  if constexpr (k == 0) {
+    if (kBits) {
+      const unsigned word = d.bits[((long long)c.pass * c.n_rows + c.lrow) * d.words + layer * d.nb + fp];
+      const unsigned lo = (word >> (4 * c.kq)) & 0xFu, hi = (word >> (16 + 4 * c.kq)) & 0xFu;
+      s.keep = ld.thr == 0 ? 0xFFu : (lo | (hi << 4));
     } else {
-      cur = prep(g);
-      slab_mfma<NTOUT>(acc, cur, pipe.cur(), lane);
+      // the counter passes through an empty volatile asm: otherwise hipcc computes every group's first rounds once,
+      // outside the pass loop, and keeps them in registers (spills)
+      unsigned kq = (unsigned)c.kq;
+      asm volatile("" : "+v"(kq));
+      s.c0 = (unsigned)c.grow; s.c1 = (unsigned)((unsigned long long)c.grow >> 32);
+      s.c2 = ((unsigned)layer << 16) | ((unsigned)fp << 2) | kq; s.c3 = d.stream + c.pass;
+      s.k0 = d.seed_lo; s.k1 = d.seed_hi;
+      philox_rounds5(s);
     }
-    pipe.advance();
+  } else if constexpr (k == 1) {
+    if (!kBits) {
+      philox_rounds5(s);
+      const unsigned o[4] = {s.c0, s.c1, s.c2, s.c3};
+      unsigned keep = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        keep |= ((o[w] & 0xFFFFu) >= ld.thr ? 1u : 0u) << (2 * w);
+        keep |= ((o[w] >> 16) >= ld.thr ? 1u : 0u) << (2 * w + 1);
+      }
+      s.keep = keep;
+    }
+  } else {
+    constexpr int r = k - 2;
+    const float a0 = tanh_f32(v0[r]), a1 = tanh_f32(v1[r]);
+    const float h0 = ((s.keep >> r) & 1u) ? a0 * ld.scale : 0.0f;
+    const float h1 = ((s.keep >> (4 + r)) & 1u) ? a1 * ld.scale : 0.0f;
+    v0[r] = h0; v1[r] = h1;
+    split_pair<r>(h0, h1, s.out);
+    if (kDot) {
+      const float t = fmaf(wp32[4 * c.kq + r], h0, wp32[16 + 4 * c.kq + r] * h1);
+      up += dot_on ? t : 0.0f;
+    }
   }
 }
 
-// The layer loops are fully unrolled straight-line code, and hipcc schedules every group's Philox counter setup
-// (and first-round products) to the top of it -- tens of long-lived registers, i.e. spills.  Passing the lane's kq
-// through an empty volatile asm ties each group's generator to its own slab step (volatile asm is not moved across
-// the step's barrier).
-__device__ __forceinline__ RowCtx pinned(const RowCtx& c) {
-  RowCtx r = c;
-  asm volatile("" : "+v"(r.kq));
-  return r;
+// One layer: NG K-groups, `cur` = the fragments of its group 0 on entry, of the next layer's group 0 on exit.
+// prep_in(g, k): micro-step k of this layer's input group g; prep_out(k): micro-step k of the NEXT layer's group 0,
+// whose raw values are this layer's acc[0], acc[1] -- final once the last slab's first tile pair is through, so
+// those steps sit in slots >= 1.  KPM / KPN: log2 row stride of this / the next matrix; NPM / NPN: (an upper bound
+// of) their 1-KB pieces per slab.
+template <int NG, int NTOUT, int KPM, int KPN, int NPM, int NPN, bool kHasOut, typename FI, typename FO>
+__device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], Pipe6& pipe, const Mat& mine, const Mat& next, int lane, Frag3& cur, Prep& st,
+                                         FI&& prep_in, FO&& prep_out) {
+  constexpr int kSlots = NTOUT / 2, kPerDma = (6 + kSlots - 1) / kSlots;
+  // VALU chunks: one per tile (NTOUT per slab).  The six micro-steps of the next group go to chunks
+  // kFirst + k * (NTOUT - kFirst) / 6; acc[0], acc[1] (the next layer's group 0) are final from chunk 2 on.
+  constexpr int kFirst = kHasOut ? 2 : 0, kAvail = NTOUT - kFirst;
+  static_assert(kAvail >= 1, "no chunk left for the next layer's group 0");
+  static_for<NG>([&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    // the next slab: K-group g + 1 of this matrix, or K-group 0 of the next one
+    auto dma = [&](auto slotc) {
+      static_for<kPerDma>([&](auto qc) {
+        constexpr int j = decltype(slotc)::value * kPerDma + decltype(qc)::value;
+        if constexpr (g + 1 < NG) {
+          if constexpr (8 * j < NPM) pipe.piece<KPM>(mine, g + 1, j, pipe.par ^ 1);
+        } else {
+          if constexpr (8 * j < NPN) pipe.piece<KPN>(next, 0, j, pipe.par ^ 1);
+        }
+      });
+    };
+    // the next group's fragments
+    auto vchunk = [&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      static_for<6>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (kFirst + k * kAvail / 6 == c) {
+          if constexpr (g + 1 < NG) prep_in(IC<g + 1>{}, IC<k>{});
+          else if constexpr (kHasOut) prep_out(IC<k>{});
+        }
+      });
+    };
+    slab_mfma<NTOUT>(acc, cur, pipe.cur(), lane, vchunk, dma);
+    pipe.advance();
+    PINN_STAMP(pipe, (NTOUT == 16 ? 0 : NTOUT == 8 ? 1 : 2));
+    cur = st.out;
+  });
 }
 
-// One forward pass for this wave's 16 rows (x6 matrix math).  Returns (u, z); v2 = tanh'ed last hidden block(s).
+// first matrix of the forward slab sequence (the pass after the last one wraps around to it); its row stride is H
+template <int H>
+__device__ __forceinline__ Mat first_mat(const PackLayout& K) {
+  return K.nh > 1 ? Mat{(unsigned)K.w(1), clog2(H / 16)} : Mat{(unsigned)K.wv0(), clog2(H / 32)};
+}
+
+// One forward pass for this wave's 16 rows (x6 matrix math).  Returns (u, z).
 template <int H, bool kBits>
 __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* smallp, const ParamLayout& L, Pipe6& pipe,
-                                                const DropDev& d, const RowCtx& c, const f32x4& xa, const f32x4& xb, bool late,
-                                                float& u, float& z) {
+                                                const DropDev& d, const RowCtx& c, const f32x4& xa, const f32x4& xb, float& u, float& z) {
   constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32;
   const int lane = c.lane, kq = c.kq;
   const SmallLayout S{L.H, L.nh};
+  const PackLayout K{L.H, L.nh};
+  constexpr int KPW = clog2(H), KPV1 = clog2((H / 2 + 63) & ~63);          // row strides: [H][H], [H/2][H]; [H/4][H/2]
+  const Mat m_v0{(unsigned)K.wv0(), clog2(H / 32)}, m_v1{(unsigned)K.wv1(), clog2(H / 64)};
+  const float* wp = smallp + S.wp();
+  const int ll = L.nh - 1;
+  float up = 0.0f;
+  Prep st;
+  Frag3 cur;
   f32x4 h[NT];
   layer_input_lds<NT>(h, w0t, smallp + S.b(0), xa, xb, lane);      // 8 -> H in exact fp32 (K = 8)
+  {   // group 0 of the first matrix layer's input: nothing to hide it under
+    const LayerDrop ld0 = layer_drop(d, c.mode, 0);
+    static_for<6>([&](auto kc) { prep_micro<kBits, true, decltype(kc)::value>(st, h[0], h[1], d, c, ld0, 0, 0, wp, up, ll == 0); });
+    cur = st.out;
+  }
 #pragma unroll 1
   for (int l = 1; l < L.nh; ++l) {
     f32x4 acc[NT];
     bias_blocks<NT>(acc, smallp + S.b(l), kq);
-    const LayerDrop ldr = layer_drop(d, c.mode, l - 1);
-    layer_x6<NP, NT>(acc, pipe, lane, late, [&](int g) {
-      const RowCtx cc = pinned(c);
-      activate_pair<kBits>(h[2 * g], h[2 * g + 1], d, cc, ldr, l - 1, g);
-      return split3(h[2 * g], h[2 * g + 1]);
-    });
+    const LayerDrop ld_in = layer_drop(d, c.mode, l - 1), ld_out = layer_drop(d, c.mode, l);
+    const bool last = l == ll;
+    const Mat mine{(unsigned)K.w(l), clog2(H / 16)}, next = last ? m_v0 : Mat{(unsigned)K.w(l + 1), clog2(H / 16)};
+    layer_x6<NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true>(
+        acc, pipe, mine, next, lane, cur, st,
+        [&](auto gc, auto kc) {
+          constexpr int g = decltype(gc)::value;
+          prep_micro<kBits, false, decltype(kc)::value>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, l - 1, g, wp, up, false);
+        },
+        [&](auto kc) { prep_micro<kBits, true, decltype(kc)::value>(st, acc[0], acc[1], d, c, ld_out, l, 0, wp, up, last); });
 #pragma unroll
     for (int t = 0; t < NT; ++t) h[t] = acc[t];
   }
-  // last hidden layer: lazily activated while the variance head's first layer multiplies; predict head on the fly
+  // variance head, first layer: its input is the last hidden layer (group 0 is prepared already); predict head on the fly
   f32x4 v1[NT2];
   bias_blocks<NT2>(v1, smallp + S.bv0(), kq);
-  float up = 0.0f;
   {
-    const int ll = L.nh - 1;
-    const LayerDrop ldr = layer_drop(d, c.mode, ll);
-    layer_x6<NP, NT2>(v1, pipe, lane, late, [&](int g) {
-      const RowCtx cc = pinned(c);
-      activate_pair<kBits>(h[2 * g], h[2 * g + 1], d, cc, ldr, ll, g);
-      up = block_dot(h[2 * g], smallp + S.wp() + (2 * g) * 16, kq, up);
-      up = block_dot(h[2 * g + 1], smallp + S.wp() + (2 * g + 1) * 16, kq, up);
-      return split3(h[2 * g], h[2 * g + 1]);
-    });
+    const LayerDrop ld_in = layer_drop(d, c.mode, ll), ld_out = layer_drop(d, c.mode, L.nh);
+    layer_x6<NP, NT2, KPW, KPV1, 3 * H / 32, 3 * H / 64, true>(
+        v1, pipe, m_v0, m_v1, lane, cur, st,
+        [&](auto gc, auto kc) {
+          constexpr int g = decltype(gc)::value;
+          prep_micro<kBits, true, decltype(kc)::value>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, ll, g, wp + 32 * g, up, true);
+        },
+        [&](auto kc) { prep_micro<kBits, false, decltype(kc)::value>(st, v1[0], v1[1], d, c, ld_out, L.nh, 0, wp, up, false); });
   }
   u = sum_kq(up) + smallp[S.bp()];
   f32x4 v2[NT4];
   bias_blocks<NT4>(v2, smallp + S.bv1(), kq);
   {
-    const LayerDrop ldr = layer_drop(d, c.mode, L.nh);
-    layer_x6<NP / 2, NT4>(v2, pipe, lane, late, [&](int g) {
-      const RowCtx cc = pinned(c);
-      activate_pair<kBits>(v1[2 * g], v1[2 * g + 1], d, cc, ldr, L.nh, g);
-      return split3(v1[2 * g], v1[2 * g + 1]);
-    });
+    const LayerDrop ld_in = layer_drop(d, c.mode, L.nh);
+    layer_x6<NP / 2, NT4, KPV1, KPW, 3 * H / 64, 3 * H / 16, false>(
+        v2, pipe, m_v1, first_mat<H>(K), lane, cur, st,
+        [&](auto gc, auto kc) {
+          constexpr int g = decltype(gc)::value;
+          prep_micro<kBits, false, decltype(kc)::value>(st, v1[2 * g], v1[2 * g + 1], d, c, ld_in, L.nh, g, wp, up, false);
+        },
+        [&](auto) {});
   }
   float zp = 0.0f;
 #pragma unroll

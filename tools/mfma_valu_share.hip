@@ -22,7 +22,9 @@ __global__ __launch_bounds__(256) void k(float* out, int iters_m, int iters_v, i
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         if (MM == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
-        else { acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, acc[t], 0, 0, 0); acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, ab, acc[t], 0, 0, 0); }
+        else if (MM == 1) { acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, acc[t], 0, 0, 0); acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, ab, acc[t], 0, 0, 0); }
+        else if (MM == 2) { acc[t & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, acc[t & 1], 0, 0, 0); acc[t & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, ab, acc[t & 1], 0, 0, 0); }   // two chains, pairs back to back
+        else { acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, acc[0], 0, 0, 0); acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, ab, acc[0], 0, 0, 0); }   // one dependent chain
       }
     }
     for (int t = 0; t < 8; ++t) s += acc[t][0];
@@ -117,6 +119,15 @@ int main() {
   test<0, 1>("f32 FMA", 80000, out);
   test<1, 1>("int mad_u64_u32 + xor", 40000, out);
   test<2, 1>("transcendental exp2 + rcp", 40000, out);
+  printf("-- same, MFMAs in two dependent chains (pairs back to back)\n");
+  test<1, 2>("int mad_u64_u32 + xor", 40000, out);
+  test<2, 2>("transcendental exp2 + rcp", 40000, out);
+  test<3, 2>("v_fma_f32", 40000, out);
+  printf("-- same, MFMAs in ONE dependent chain\n");
+  test<1, 3>("int mad_u64_u32 + xor", 40000, out);
+  test<2, 3>("transcendental exp2 + rcp", 40000, out);
+  test<3, 3>("v_fma_f32", 40000, out);
+  printf("-- single pinned instructions against the independent bf16 stream\n");
   test<3, 1>("v_fma_f32", 40000, out);
   test<4, 1>("v_pk_fma_f32", 40000, out);
   test<5, 1>("v_add_f32", 40000, out);

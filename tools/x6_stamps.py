@@ -1,0 +1,26 @@
+"""Diagnostic: per-wave cycle split of the x6 forward (needs a -DPINN_X6_STAMP build loaded via PINN_HIP_LIB)."""
+import ctypes, os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R, os.path.join(R, "tests"), os.path.join(R, "oracle")]
+import torch
+import pinn_amd
+from pinn_amd import _lib
+import hip_helpers as hh
+import pinn_oracle as O
+lib = _lib.load()
+H, nh, N = 256, 3, 1_000_000
+P = O.init_params([8, H, H, H, 1], seed=1)
+fp = hh.flat_params(P, H, nh).to(hh.dev())
+x = torch.rand(N, 8, device=hh.dev())
+drop = hh.dropout_struct(1, [0.2] * 4, seed=1, stream_id=2)
+for _ in range(3):
+    hh.forward(lib, H, nh, fp, x, drop, precision=2)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 32)()
+lib.pinn_x6_debug_read.restype = ctypes.c_int
+print("rc", lib.pinn_x6_debug_read(buf))
+tiles = -(-N // 128 // 256)
+print("block 0: ~%d tiles; ticks per slab step (incl. barrier): hidden (16 steps/tile), Wv0 (8), Wv1 (4); rest = input layer, heads, stores per tile" % tiles)
+for w in (0, 4):
+    s = [buf[w * 4 + k] for k in range(4)]
+    print("wave %d: hidden %.0f  wv0 %.0f  wv1 %.0f  | per tile: hidden %.0f wv0 %.0f wv1 %.0f rest %.0f total %.0f" % (
+        w, s[0] / (16 * tiles), s[1] / (8 * tiles), s[2] / (4 * tiles), s[0] / tiles, s[1] / tiles, s[2] / tiles, s[3] / tiles, sum(s) / tiles))
