@@ -20,6 +20,7 @@ SOURCES = [
     ("pinn_train.hip", []),
     ("pinn_bf16.hip", []),
     ("pinn_x6.hip", []),
+    ("pinn_x6_train.hip", []),
     ("pinn_optim.hip", []),
 ]
 HEADERS = ["pinn_mlp_core.h", "pinn_bf16_core.h", "pinn_x6_core.h", os.path.join("..", "..", "include", "pinn_hip.h")]

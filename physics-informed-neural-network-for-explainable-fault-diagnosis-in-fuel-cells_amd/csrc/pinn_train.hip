@@ -425,7 +425,8 @@ struct Workspace {
 static Workspace plan_workspace(const pinn_net_t* net, long long n_rows) {
   Workspace w;
   const long long H = net->hidden, nh = net->n_hidden;
-  w.t16 = (n_rows + kTileRows - 1) / kTileRows * 4;
+  // whole workgroup tiles: 64 rows (4 wave tiles), 128 (8) for the x6 chain
+  w.t16 = net->precision == PINN_PREC_F32X6 ? (n_rows + 127) / 128 * 8 : (n_rows + kTileRows - 1) / kTileRows * 4;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
   w.off_stash_h = take((size_t)nh * w.t16 * H * 16 * 4);
@@ -453,7 +454,6 @@ static int check_net_t(const pinn_net_t* net) {
   if (net->n_hidden < 1 || net->n_hidden > 8) return PINN_E_ARCH;
   if (net->precision < PINN_PREC_FP32 || net->precision > PINN_PREC_F32X6) return PINN_E_ARG;
   if (net->precision != PINN_PREC_FP32 && !net->d_packed) return PINN_E_ARG;
-  if (net->precision == PINN_PREC_F32X6) return PINN_E_ARCH;   // training in x6 precision: not implemented yet
   return PINN_OK;
 }
 
@@ -494,6 +494,8 @@ static int dispatch_wgrad(const WgradArgs& a, hipStream_t st) {
 }  // namespace pinn
 
 namespace pinn {
+int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y, long long n_rows,
+                          long long n_global, const DropDev& drop, const TrainBuffers& b, int* grid_out, void* stream);   // pinn_x6_train.hip
 int launch_train_bf16(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y, long long n_rows,
                       long long n_global, const DropDev& drop, const TrainBuffers& b, unsigned phases, int* grid_out, void* stream);
 }
@@ -567,7 +569,20 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     hipError_t eb = hipGetLastError();
     return eb == hipSuccess ? PINN_OK : (int)eb;
   }
-  if (phases & PINN_PHASE_CHAIN) {
+  if (net->precision == PINN_PREC_F32X6) {
+    // fp32-accurate chain on the bf16 matrix cores; the weight-gradient and finalize kernels below are shared
+    if (phases & PINN_PHASE_CHAIN) {
+      TrainBuffers b{};
+      b.stash_h = a.stash_h; b.stash_v1 = a.stash_v1; b.stash_v2 = a.stash_v2;
+      b.dpre_h = a.dpre_h; b.dpre_v1 = a.dpre_v1; b.dpre_v2 = a.dpre_v2;
+      b.keep = a.keep; b.du = a.du; b.dz = a.dz; b.loss_part = a.loss_part;
+      b.slabs = (float*)(base + w.off_slabs); b.t16 = w.t16; b.n_slices = w.n_slices;
+      if ((rc = launch_train_chain_x6(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, &grid, stream))) return rc;
+    } else {
+      const long long nt = (n_rows + 127) / 128;
+      grid = (int)(nt < cu_count() ? nt : cu_count());
+    }
+  } else if (phases & PINN_PHASE_CHAIN) {
     const bool bits = a.drop.mode == PINN_DROP_BITS;
     if (H == 256) {
       if (bits) hipLaunchKernelGGL((train_chain_kernel<256, true>), dim3(grid), dim3(kThreads), 0, st, a);

@@ -276,10 +276,16 @@ __device__ __forceinline__ void philox_rounds5(Prep& s) {
     s.k0 += 0x9E3779B9u; s.k1 += 0xBB67AE85u;
   }
 }
-// wp32: the predict head's 32 weights of this group (LDS) when kDot; the dot is accumulated only if dot_on
+// A kept activation that is exactly 0 is stashed as FLT_MIN: the backward pass reads "dropped" off h == 0 (no keep-bit
+// stash), and FLT_MIN contributes nothing anywhere (1 - a^2 == 1, products with it underflow).
+__device__ __forceinline__ float stash_value(float h, bool kept) {
+  return kept ? (h == 0.0f ? 1.17549435e-38f : h) : 0.0f;
+}
+// wp32: the predict head's 32 weights of this group (LDS) when kDot; the dot is accumulated only if dot_on.
+// sp (training only, else nullptr): this lane's slot of the group's first feature in the activation stash.
 template <bool kBits, bool kDot, int k>
 __device__ __forceinline__ void prep_micro(Prep& s, f32x4& v0, f32x4& v1, const DropDev& d, const RowCtx& c, const LayerDrop ld,
-                                           int layer, int fp, const float* wp32, float& up, bool dot_on) {
+                                           int layer, int fp, const float* wp32, float& up, bool dot_on, float* sp = nullptr) {
   if constexpr (k == 0) {
     if (kBits) {
       const unsigned word = d.bits[((long long)c.pass * c.n_rows + c.lrow) * d.words + layer * d.nb + fp];
@@ -310,10 +316,15 @@ __device__ __forceinline__ void prep_micro(Prep& s, f32x4& v0, f32x4& v1, const 
   } else {
     constexpr int r = k - 2;
     const float a0 = tanh_f32(v0[r]), a1 = tanh_f32(v1[r]);
-    const float h0 = ((s.keep >> r) & 1u) ? a0 * ld.scale : 0.0f;
-    const float h1 = ((s.keep >> (4 + r)) & 1u) ? a1 * ld.scale : 0.0f;
+    const bool k0 = (s.keep >> r) & 1u, k1 = (s.keep >> (4 + r)) & 1u;
+    const float h0 = k0 ? a0 * ld.scale : 0.0f;
+    const float h1 = k1 ? a1 * ld.scale : 0.0f;
     v0[r] = h0; v1[r] = h1;
     split_pair<r>(h0, h1, s.out);
+    if (sp) {
+      sp[r * 16] = stash_value(h0, k0);
+      sp[(16 + r) * 16] = stash_value(h1, k1);
+    }
     if (kDot) {
       const float t = fmaf(wp32[4 * c.kq + r], h0, wp32[16 + 4 * c.kq + r] * h1);
       up += dot_on ? t : 0.0f;
@@ -371,10 +382,25 @@ __device__ __forceinline__ Mat first_mat(const PackLayout& K) {
   return K.nh > 1 ? Mat{(unsigned)K.w(1), clog2(H / 16)} : Mat{(unsigned)K.wv0(), clog2(H / 32)};
 }
 
-// One forward pass for this wave's 16 rows (x6 matrix math).  Returns (u, z).
-template <int H, bool kBits>
+// stash of one 16-row tile: activations and d(pre-activations) as [layer][T16][F][16] fp32 (the fp32 kernels' layout)
+struct StashX {
+  float* h; float* v1; float* v2;
+  float* dh; float* dv1; float* dv2;
+  long long t16_total, t16;
+  __device__ __forceinline__ float* act(int layer, int H_, int lane) const {      // hidden layer `layer`, feature 0
+    return tiled_ptr(h + (long long)layer * t16_total * H_ * 16, t16, H_, lane);
+  }
+  __device__ __forceinline__ float* dact(int layer, int H_, int lane) const {
+    return tiled_ptr(dh + (long long)layer * t16_total * H_ * 16, t16, H_, lane);
+  }
+};
+
+// One forward pass for this wave's 16 rows (x6 matrix math).  Returns (u, z); TRAIN: activations go to the stash,
+// v2 = the tanh'ed last variance block(s), and the weight stream continues with the backward pass's first matrix.
+template <int H, bool kBits, bool TRAIN = false>
 __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* smallp, const ParamLayout& L, Pipe6& pipe,
-                                                const DropDev& d, const RowCtx& c, const f32x4& xa, const f32x4& xb, float& u, float& z) {
+                                                const DropDev& d, const RowCtx& c, const f32x4& xa, const f32x4& xb, float& u, float& z,
+                                                const StashX* sx = nullptr, f32x4* v2_out = nullptr) {
   constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32;
   const int lane = c.lane, kq = c.kq;
   const SmallLayout S{L.H, L.nh};
@@ -390,7 +416,8 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
   layer_input_lds<NT>(h, w0t, smallp + S.b(0), xa, xb, lane);      // 8 -> H in exact fp32 (K = 8)
   {   // group 0 of the first matrix layer's input: nothing to hide it under
     const LayerDrop ld0 = layer_drop(d, c.mode, 0);
-    static_for<6>([&](auto kc) { prep_micro<kBits, true, decltype(kc)::value>(st, h[0], h[1], d, c, ld0, 0, 0, wp, up, ll == 0); });
+    float* sp = TRAIN ? sx->act(0, H, lane) : nullptr;
+    static_for<6>([&](auto kc) { prep_micro<kBits, true, decltype(kc)::value>(st, h[0], h[1], d, c, ld0, 0, 0, wp, up, ll == 0, sp); });
     cur = st.out;
   }
 #pragma unroll 1
@@ -400,13 +427,16 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
     const LayerDrop ld_in = layer_drop(d, c.mode, l - 1), ld_out = layer_drop(d, c.mode, l);
     const bool last = l == ll;
     const Mat mine{(unsigned)K.w(l), clog2(H / 16)}, next = last ? m_v0 : Mat{(unsigned)K.w(l + 1), clog2(H / 16)};
+    float* sp_in = TRAIN ? sx->act(l - 1, H, lane) : nullptr;
+    float* sp_out = TRAIN ? sx->act(l, H, lane) : nullptr;
     layer_x6<NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true>(
         acc, pipe, mine, next, lane, cur, st,
         [&](auto gc, auto kc) {
           constexpr int g = decltype(gc)::value;
-          prep_micro<kBits, false, decltype(kc)::value>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, l - 1, g, wp, up, false);
+          prep_micro<kBits, false, decltype(kc)::value>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, l - 1, g, wp, up, false,
+                                                        TRAIN ? sp_in + 32 * g * 16 : nullptr);
         },
-        [&](auto kc) { prep_micro<kBits, true, decltype(kc)::value>(st, acc[0], acc[1], d, c, ld_out, l, 0, wp, up, last); });
+        [&](auto kc) { prep_micro<kBits, true, decltype(kc)::value>(st, acc[0], acc[1], d, c, ld_out, l, 0, wp, up, last, sp_out); });
 #pragma unroll
     for (int t = 0; t < NT; ++t) h[t] = acc[t];
   }
@@ -415,34 +445,234 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
   bias_blocks<NT2>(v1, smallp + S.bv0(), kq);
   {
     const LayerDrop ld_in = layer_drop(d, c.mode, ll), ld_out = layer_drop(d, c.mode, L.nh);
+    float* sp_in = TRAIN ? sx->act(ll, H, lane) : nullptr;
+    float* sp_out = TRAIN ? tiled_ptr(sx->v1, sx->t16, H / 2, lane) : nullptr;
     layer_x6<NP, NT2, KPW, KPV1, 3 * H / 32, 3 * H / 64, true>(
         v1, pipe, m_v0, m_v1, lane, cur, st,
         [&](auto gc, auto kc) {
           constexpr int g = decltype(gc)::value;
-          prep_micro<kBits, true, decltype(kc)::value>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, ll, g, wp + 32 * g, up, true);
+          prep_micro<kBits, true, decltype(kc)::value>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, ll, g, wp + 32 * g, up, true,
+                                                       TRAIN ? sp_in + 32 * g * 16 : nullptr);
         },
-        [&](auto kc) { prep_micro<kBits, false, decltype(kc)::value>(st, v1[0], v1[1], d, c, ld_out, L.nh, 0, wp, up, false); });
+        [&](auto kc) { prep_micro<kBits, false, decltype(kc)::value>(st, v1[0], v1[1], d, c, ld_out, L.nh, 0, wp, up, false, sp_out); });
   }
   u = sum_kq(up) + smallp[S.bp()];
   f32x4 v2[NT4];
   bias_blocks<NT4>(v2, smallp + S.bv1(), kq);
   {
     const LayerDrop ld_in = layer_drop(d, c.mode, L.nh);
-    layer_x6<NP / 2, NT4, KPV1, KPW, 3 * H / 64, 3 * H / 16, false>(
-        v2, pipe, m_v1, first_mat<H>(K), lane, cur, st,
-        [&](auto gc, auto kc) {
-          constexpr int g = decltype(gc)::value;
-          prep_micro<kBits, false, decltype(kc)::value>(st, v1[2 * g], v1[2 * g + 1], d, c, ld_in, L.nh, g, wp, up, false);
-        },
-        [&](auto) {});
+    float* sp_in = TRAIN ? tiled_ptr(sx->v1, sx->t16, H / 2, lane) : nullptr;
+    auto prep_in = [&](auto gc, auto kc) {
+      constexpr int g = decltype(gc)::value;
+      prep_micro<kBits, false, decltype(kc)::value>(st, v1[2 * g], v1[2 * g + 1], d, c, ld_in, L.nh, g, wp, up, false,
+                                                    TRAIN ? sp_in + 32 * g * 16 : nullptr);
+    };
+    if constexpr (TRAIN) {
+      // the backward pass starts with Wv1^T: [H/2][H/4], row stride padded to 64
+      constexpr int KPT1 = clog2((H / 4 + 63) & ~63);
+      const Mat m_t1{(unsigned)K.wv1t(), clog2(H / 32)};
+      layer_x6<NP / 2, NT4, KPV1, KPT1, 3 * H / 64, 3 * H / 32, false>(v2, pipe, m_v1, m_t1, lane, cur, st, prep_in, [&](auto) {});
+    } else {
+      layer_x6<NP / 2, NT4, KPV1, KPW, 3 * H / 64, 3 * H / 16, false>(v2, pipe, m_v1, first_mat<H>(K), lane, cur, st, prep_in, [&](auto) {});
+    }
   }
   float zp = 0.0f;
+  float* sp2 = TRAIN ? tiled_ptr(sx->v2, sx->t16, H / 4, lane) : nullptr;
 #pragma unroll
   for (int t = 0; t < NT4; ++t) {
     activate_tanh(v2[t]);
     zp = block_dot(v2[t], smallp + S.wv2() + t * 16, kq, zp);
+    if (TRAIN) {
+      store_block(sp2, t, v2[t]);
+      v2_out[t] = v2[t];
+    }
   }
   z = sum_kq(zp) + smallp[S.bv2()];
+}
+
+// ---------------------------------------------------------------------------------------
+// backward pass
+// ---------------------------------------------------------------------------------------
+// This wave's LDS copies of stash blocks (32 features x 16 rows fp32 = 2 KB, the global layout as it is): the block
+// of the group that will be prepared in the NEXT slab step streams in by LDS-DMA during this one (retired by the
+// step's barrier), so the backward chunks never wait on a global load.
+struct StashRing {
+  char* lds;      // 2 x 2048 B of this wave
+  int lane;
+  __device__ __forceinline__ void fetch(const float* block, int buf) const {
+    const char* src = reinterpret_cast<const char*>(block) + lane * 16;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + buf * 2048), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + 1024), (lptr_t)(lds + buf * 2048 + 1024), 16, 0, 0);
+  }
+  // feature 16 b + 4 kq + r of the block, this lane's row
+  __device__ __forceinline__ float read(int buf, int b, int r) const {
+    return *reinterpret_cast<const float*>(lds + buf * 2048 + ((16 * b + 4 * (lane >> 4) + r) * 16 + (lane & 15)) * 4);
+  }
+};
+
+// micro-step k of a backward group: raw d0, d1 = d loss / d h (two 16-feature blocks) -> d pre-activation in place,
+// stashed for the weight-gradient kernels (dsp) and split for the next matrix.  h = post-dropout activation from
+// the stash copy in LDS: dropped <=> h == 0, a = h / scale, d pre = d h * scale * (1 - a^2).
+template <int k>
+__device__ __forceinline__ void bprep_micro(Prep& s, f32x4& d0, f32x4& d1, const StashRing& ring, int buf, float* dsp, float scale,
+                                            float inv_scale) {
+  if constexpr (k >= 2) {
+    constexpr int r = k - 2;
+    const float h0 = ring.read(buf, 0, r), h1 = ring.read(buf, 1, r);
+    const float a0 = h0 * inv_scale, a1 = h1 * inv_scale;
+    const float g0 = d0[r] * (scale * (1.0f - a0 * a0)), g1 = d1[r] * (scale * (1.0f - a1 * a1));
+    const float p0 = h0 != 0.0f ? g0 : 0.0f, p1 = h1 != 0.0f ? g1 : 0.0f;
+    d0[r] = p0; d1[r] = p1;
+    dsp[r * 16] = p0;
+    dsp[(16 + r) * 16] = p1;
+    split_pair<r>(p0, p1, s.out);
+  }
+}
+
+// Backward chain of this wave's 16 rows: d pre-activations of every layer to the stash.  du, dz = d loss / d (u, z);
+// v2 = tanh'ed last variance blocks.  The weight stream arrives positioned on Wv1^T and leaves on the forward pass's
+// first matrix.
+template <int H>
+__device__ __forceinline__ void backward_pass_x6(const float* smallp, const ParamLayout& L, Pipe6& pipe, const DropDev& d, int mode,
+                                                 const StashX& sx, const StashRing& ring, int lane, float du, float dz, f32x4* v2) {
+  constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32;
+  constexpr int NG1 = (H / 4) / 32 > 0 ? (H / 4) / 32 : 1;                 // K-groups of Wv1^T (K = H/4)
+  constexpr int KPW = clog2(H), KPT0 = clog2((H / 2 + 63) & ~63), KPT1 = clog2((H / 4 + 63) & ~63);
+  const int kq = lane >> 4;
+  const SmallLayout S{L.H, L.nh};
+  const PackLayout K{L.H, L.nh};
+  const int nh = L.nh;
+  const int n_blocks = NP / 2 + (nh - 1) * NP;                             // stash blocks that feed a matrix, in order
+  // i-th stash block in backward order: v1 groups 0 .. NP/2-1, then hidden layers nh-1 .. 1, groups 0 .. NP-1
+  auto block_ptr = [&](int i) -> const float* {
+    if (i < NP / 2) return sx.v1 + (sx.t16 * (H / 2) + 32 * i) * 16;
+    const int j = i - NP / 2, layer = nh - 1 - j / NP, g = j % NP;
+    return sx.h + ((long long)layer * sx.t16_total * H + sx.t16 * H + 32 * g) * 16;
+  };
+  auto fetch_block = [&](int i) {
+    if (i < n_blocks) ring.fetch(block_ptr(i), i & 1);
+  };
+  fetch_block(0);
+
+  Prep st;
+  Frag3 cur;
+  // ---- d pre_v2 = wv2 * dz * (1 - v2^2): the B operand of Wv1^T, all in registers
+  {
+    float* sp = tiled_ptr(sx.dv2, sx.t16, H / 4, lane);
+#pragma unroll
+    for (int t = 0; t < NT4; ++t) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(smallp + S.wv2() + t * 16 + 4 * kq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v2[t][r] = w[r] * dz * (1.0f - v2[t][r] * v2[t][r]);
+      store_block(sp, t, v2[t]);
+    }
+    if constexpr (NT4 >= 2) cur = split3(v2[0], v2[1]);
+    else { const f32x4 zero = {0.f, 0.f, 0.f, 0.f}; cur = split3(v2[0], zero); }     // H = 128: K = 32 of a padded 64... one real block
+  }
+  const Mat m_t1{(unsigned)K.wv1t(), clog2(H / 32)}, m_t0{(unsigned)K.wv0t(), clog2(H / 16)};
+  const Mat m_first = first_mat<H>(K);
+
+  // ---- d h_v1 = Wv1^T d pre_v2; lazily -> d pre_v1 (stash block i = its group)
+  f32x4 dpv1[NT2];
+  zero_blocks<NT2>(dpv1);
+  {
+    const LayerDrop ldv = layer_drop(d, mode, nh);
+    const float scale = ldv.scale, inv_scale = 1.0f / scale;
+    float* dsp = tiled_ptr(sx.dv1, sx.t16, H / 2, lane);
+    layer_x6<NG1, NT2, KPT1, KPT0, 3 * H / 32, 3 * H / 16, true>(
+        dpv1, pipe, m_t1, m_t0, lane, cur, st,
+        [&](auto gc, auto kc) {
+          constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
+          if constexpr (k >= 2 && 2 * g + 1 < NT4) split_pair<k - 2>(v2[2 * g][k - 2], v2[2 * g + 1][k - 2], st.out);
+        },
+        [&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          if constexpr (k == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // block 0 was requested at the top of this pass
+            fetch_block(1);
+          }
+          bprep_micro<k>(st, dpv1[0], dpv1[1], ring, 0, dsp, scale, inv_scale);
+        });
+  }
+
+  // ---- d h_last = w_p du + Wv0^T d pre_v1; lazily -> d pre of the last hidden layer
+  f32x4 dh[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(smallp + S.wp() + t * 16 + 4 * kq);
+    dh[t] = w * du;
+  }
+  {
+    const LayerDrop ldv = layer_drop(d, mode, nh), ldh = layer_drop(d, mode, nh - 1);
+    const float scale = ldv.scale, inv_scale = 1.0f / scale, scale_o = ldh.scale, inv_scale_o = 1.0f / scale_o;
+    float* dsp = tiled_ptr(sx.dv1, sx.t16, H / 2, lane);
+    float* dsp_o = sx.dact(nh - 1, H, lane);
+    const Mat next = nh > 1 ? Mat{(unsigned)K.wt(nh - 1), clog2(H / 16)} : m_first;
+    layer_x6<NP / 2, NT, KPT0, KPW, 3 * H / 16, 3 * H / 16, true>(
+        dh, pipe, m_t0, next, lane, cur, st,
+        [&](auto gc, auto kc) {
+          constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
+          if constexpr (k == 0) fetch_block(g + 1);
+          bprep_micro<k>(st, dpv1[2 * g], dpv1[2 * g + 1], ring, g & 1, dsp + 32 * g * 16, scale, inv_scale);
+        },
+        [&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          if (nh > 1) {
+            if constexpr (k == 0) fetch_block(NP / 2 + 1);
+            bprep_micro<k>(st, dh[0], dh[1], ring, (NP / 2) & 1, dsp_o, scale_o, inv_scale_o);
+          }
+        });
+  }
+
+  // ---- hidden layers nh-1 .. 1: d h_{l-1} = W_l^T d pre_l
+#pragma unroll 1
+  for (int l = nh - 1; l >= 1; --l) {
+    f32x4 acc[NT];
+    zero_blocks<NT>(acc);
+    const LayerDrop ld_in = layer_drop(d, mode, l), ld_out = layer_drop(d, mode, l - 1);
+    const float scale = ld_in.scale, inv_scale = 1.0f / scale, scale_o = ld_out.scale, inv_scale_o = 1.0f / scale_o;
+    float* dsp = sx.dact(l, H, lane);
+    float* dsp_o = sx.dact(l - 1, H, lane);
+    const int base = NP / 2 + (nh - 1 - l) * NP;           // stash block index of this layer's group 0
+    const Mat mine{(unsigned)K.wt(l), clog2(H / 16)}, next = l > 1 ? Mat{(unsigned)K.wt(l - 1), clog2(H / 16)} : m_first;
+    layer_x6<NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true>(
+        acc, pipe, mine, next, lane, cur, st,
+        [&](auto gc, auto kc) {
+          constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
+          if constexpr (k == 0) fetch_block(base + g + 1);
+          bprep_micro<k>(st, dh[2 * g], dh[2 * g + 1], ring, (base + g) & 1, dsp + 32 * g * 16, scale, inv_scale);
+        },
+        [&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          if (l > 1) {
+            if constexpr (k == 0) fetch_block(base + NP + 1);
+            bprep_micro<k>(st, acc[0], acc[1], ring, (base + NP) & 1, dsp_o, scale_o, inv_scale_o);
+          }
+        });
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dh[t] = acc[t];
+  }
+
+  // ---- layer 0: d pre_0 = d h_0 * tanh' (no matrix follows: plain loads, all issued before the arithmetic)
+  {
+    const LayerDrop ld0 = layer_drop(d, mode, 0);
+    const float scale = ld0.scale, inv_scale = 1.0f / scale;
+    const float* hp = sx.act(0, H, lane);
+    float* dsp = sx.dact(0, H, lane);
+    f32x4 hl[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) load_block(hp, t, hl[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a0 = hl[t][r] * inv_scale;
+        const float g0 = dh[t][r] * (scale * (1.0f - a0 * a0));
+        dh[t][r] = hl[t][r] != 0.0f ? g0 : 0.0f;
+      }
+      store_block(dsp, t, dh[t]);
+    }
+  }
 }
 
 }  // namespace x6

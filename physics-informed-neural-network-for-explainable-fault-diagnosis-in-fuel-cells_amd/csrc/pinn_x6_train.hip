@@ -1,0 +1,156 @@
+// pinn_x6_train.hip -- train_dnn's forward + aleatoric_loss + backward chain (01:949-953) with fp32-accurate
+// matrix products on the bf16 matrix cores (pinn_net_t.precision = PINN_PREC_F32X6; see pinn_x6_core.h).
+// Same stash layout and outputs as train_chain_kernel (pinn_train.hip): the weight-gradient and finalize
+// kernels that follow are shared.
+#include "pinn_x6_core.h"
+
+namespace pinn {
+namespace x6 {
+
+constexpr int kLossTermsX = 8;   // nll, |logvar|, (y-u)^2, du, dz, spare... (= kLossTerms of pinn_train.hip)
+
+struct TrainArgsX {
+  const float* params;
+  const float* x;
+  const float* y;
+  long long n_rows, n_global;
+  int H, nh;
+  DropDev drop;
+  TrainBuffers b;
+};
+
+template <int H, bool kBits>
+__global__ __launch_bounds__(kThreadsX, 2) void train_chain_x6_kernel(TrainArgsX a, const __bf16* packed) {
+  constexpr int NT4 = H / 64;
+  constexpr int kSmallBytes = kMaxSmall * 4, kW0Bytes = 8 * kW0Stride * 4, kRingBytes = 8 * 2 * 2048, kRedBytes = 8 * kLossTermsX * 8;
+  constexpr int kSlabAt = (kSmallBytes + kW0Bytes + kRedBytes + kRingBytes + 1023) & ~1023;
+  __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * kSlabBytes];
+  float* small = reinterpret_cast<float*>(smem);
+  float* w0t = reinterpret_cast<float*>(smem + kSmallBytes);
+  double (*red)[kLossTermsX] = reinterpret_cast<double (*)[kLossTermsX]>(smem + kSmallBytes + kW0Bytes);
+  char* ring_lds = smem + kSmallBytes + kW0Bytes + kRedBytes;
+  char* lds_w = smem + kSlabAt;
+  ParamLayout L{a.H, a.nh};
+  PackLayout K{a.H, a.nh};
+  {   // small parameter vectors and W0^T -> LDS
+    const SmallLayout S{L.H, L.nh};
+    const int Hh = L.H, tid = threadIdx.x;
+    for (int l = 0; l < L.nh; ++l)
+      for (int i = tid; i < Hh; i += kThreadsX) small[S.b(l) + i] = a.params[L.b(l) + i];
+    for (int i = tid; i < Hh; i += kThreadsX) small[S.wp() + i] = a.params[L.wp() + i];
+    for (int i = tid; i < Hh / 2; i += kThreadsX) small[S.bv0() + i] = a.params[L.bv0() + i];
+    for (int i = tid; i < Hh / 4; i += kThreadsX) { small[S.bv1() + i] = a.params[L.bv1() + i]; small[S.wv2() + i] = a.params[L.wv2() + i]; }
+    if (tid == 0) { small[S.bp()] = a.params[L.bp()]; small[S.bv2()] = a.params[L.bv2()]; }
+    for (int e = tid; e < Hh * 8; e += kThreadsX) w0t[(e & 7) * kW0Stride + (e >> 3)] = a.params[L.w0() + e];
+    __syncthreads();
+  }
+  Pipe6 pipe;
+  pipe.packed = (const char*)packed; pipe.copy_bytes = (unsigned)(K.total() * 2); pipe.lds = lds_w;
+  pipe.init(threadIdx.x);
+  pipe.prime<clog2(H)>(first_mat<H>(K));
+
+  const int lane = threadIdx.x & 63, wave = pipe.wave, kq = lane >> 4;
+  const StashRing ring{ring_lds + wave * 4096, lane};
+  const float inv_n = (float)(1.0 / (double)a.n_global);
+  float s_nll = 0.f, s_abs = 0.f, s_mse = 0.f, s_du = 0.f, s_dz = 0.f;
+
+  const long long n_tiles = (a.n_rows + kTileRowsX - 1) / kTileRowsX;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long t16 = tile * 8 + wave;
+    const long long lrow = t16 * 16 + (lane & 15);
+    const bool valid = lrow < a.n_rows;
+    const long long srow = valid ? lrow : a.n_rows - 1;
+    const f32x4 xa = reinterpret_cast<const f32x4*>(a.x)[srow * 2];
+    const f32x4 xb = reinterpret_cast<const f32x4*>(a.x)[srow * 2 + 1];
+    const float yv = a.y[srow];
+    const RowCtx c{lane, kq, a.drop.row_offset + lrow, srow, a.n_rows, 0u, a.drop.mode};
+    const StashX sx{(float*)a.b.stash_h, (float*)a.b.stash_v1, (float*)a.b.stash_v2, (float*)a.b.dpre_h, (float*)a.b.dpre_v1, (float*)a.b.dpre_v2,
+                    a.b.t16, t16};
+
+    // ------------------------------------------------------------------ forward (activations stashed)
+    float u, z;
+    f32x4 v2[NT4];
+    forward_pass_x6<H, kBits, true>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z, &sx, v2);
+
+    // ------------------------------------------------------------------ aleatoric_loss (01:916-927) and its gradient
+    float du = 0.f, dz = 0.f;
+    {
+      const float sp = softplus_f32(z);
+      const float var = sp + 1e-6f;
+      const float s = logf(var);                 // logvar
+      const float prec = expf(-s);               // precision = exp(-logvar), 01:919
+      const float e = yv - u;
+      if (valid) {
+        du = -(prec * e) * inv_n;
+        const float sgn = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+        const float ds = (-0.5f * prec * e * e + 0.5f + 0.01f * sgn) * inv_n;
+        // d logvar / dz = softplus'(z) / (softplus(z) + 1e-6); torch: softplus' = 1 above threshold 20
+        const float sig = z > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-z));
+        dz = ds * sig / var;
+        if (kq == 0) {
+          s_nll += 0.5f * prec * e * e + 0.5f * s;
+          s_abs += fabsf(s);
+          s_mse += e * e;
+          s_du += du;
+          s_dz += dz;
+        }
+      }
+      if (lane < 16) { a.b.du[t16 * 16 + lane] = du; a.b.dz[t16 * 16 + lane] = dz; }
+    }
+
+    // ------------------------------------------------------------------ backward chain
+    backward_pass_x6<H>(small, L, pipe, a.drop, a.drop.mode, sx, ring, lane, du, dz, v2);
+  }
+
+  // ---------------------------------------------------------------------- loss partial sums of this workgroup
+  float terms[5] = {s_nll, s_abs, s_mse, s_du, s_dz};
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    double v = (double)terms[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kLossTermsX) {
+    double t = 0.0;
+    if (threadIdx.x < 5)
+      for (int w = 0; w < 8; ++w) t += red[w][threadIdx.x];
+    a.b.loss_part[(long long)blockIdx.x * kLossTermsX + threadIdx.x] = t;
+  }
+}
+
+void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st);   // pinn_x6.hip
+
+}  // namespace x6
+
+// chain phase of pinn_mlp_train_grads for PINN_PREC_F32X6; *grid_out = workgroups (= loss partials)
+int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y, long long n_rows,
+                          long long n_global, const DropDev& drop, const TrainBuffers& b, int* grid_out, void* stream) {
+  using namespace x6;
+  hipStream_t st = (hipStream_t)stream;
+  launch_pack_x6(net, d_params, st);
+  TrainArgsX a{};
+  a.params = d_params; a.x = d_x; a.y = d_y; a.n_rows = n_rows; a.n_global = n_global; a.H = net->hidden; a.nh = net->n_hidden;
+  a.drop = drop; a.b = b;
+  int cus = 0, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  if (cus <= 0) cus = 256;
+  const long long n_tiles = (n_rows + kTileRowsX - 1) / kTileRowsX;
+  const int grid = (int)(n_tiles < cus ? n_tiles : cus);
+  *grid_out = grid;
+  const __bf16* packed = (const __bf16*)net->d_packed;
+  const bool bits = drop.mode == PINN_DROP_BITS;
+  if (net->hidden == 256) {
+    if (bits) hipLaunchKernelGGL((train_chain_x6_kernel<256, true>), dim3(grid), dim3(kThreadsX), 0, st, a, packed);
+    else hipLaunchKernelGGL((train_chain_x6_kernel<256, false>), dim3(grid), dim3(kThreadsX), 0, st, a, packed);
+  } else {
+    if (bits) hipLaunchKernelGGL((train_chain_x6_kernel<128, true>), dim3(grid), dim3(kThreadsX), 0, st, a, packed);
+    else hipLaunchKernelGGL((train_chain_x6_kernel<128, false>), dim3(grid), dim3(kThreadsX), 0, st, a, packed);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PINN_OK : (int)e;
+}
+
+}  // namespace pinn

@@ -78,3 +78,61 @@ def test_mc_dropout_x6(lib):
     np.testing.assert_allclose(o[0], np.asarray(pm).reshape(-1), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(o[1], np.asarray(au).reshape(-1), rtol=1e-4)
     np.testing.assert_allclose(o[2], np.asarray(eu).reshape(-1), rtol=1e-3, atol=1e-5)
+
+
+def _check_grads(got_flat, want_list, H, nh, rtol, atol_scale=1e-6):
+    import hip_helpers as hh
+    got = hh.unflat(got_flat.cpu(), H, nh)
+    for n, g, w in zip(O.param_names(nh), got, want_list):
+        w = torch.as_tensor(w)
+        scale = float(w.abs().max()) + 1e-30
+        err = float((g - w).abs().max())
+        assert err <= rtol * scale + atol_scale * scale, (n, err, scale)
+
+
+@pytest.mark.parametrize("H,nh,N,mode", [(256, 3, 1000, 1), (128, 3, 333, 1), (256, 2, 129, 0), (128, 4, 4096, 1), (256, 1, 64, 1),
+                                         (128, 1, 200, 1)])
+def test_train_grads_x6_vs_oracle_autograd(lib, H, nh, N, mode):
+    """Training step with the x6 chain (forward + NLL + backward; fp32 weight-gradient kernels on its stash): loss and
+    all 14 gradient tensors against torch autograd on the oracle -- the SAME tolerances as the exact-fp32 kernels
+    (tests/test_gpu_train.py)."""
+    import hip_helpers as hh
+    from pinn_amd import synth
+    P = O.init_params([8] + [H] * nh + [1], seed=H + nh)
+    ds = synth.make_dataset(N, (), seed=5)
+    x, y = ds[0], ds[1].reshape(-1)
+    pl = [0.2] * (nh + 1)
+    seed, stream, row0 = 987654321987, 42, 12345
+    drop = hh.dropout_struct(mode, pl, seed=seed, stream_id=stream, row_offset=row0)
+    fp, xd, yd = hh.flat_params(P, H, nh).to(hh.dev()), x.to(hh.dev()).contiguous(), y.to(hh.dev()).contiguous()
+    grads, loss = hh.train_grads(lib, H, nh, fp, xd, yd, drop, precision=2)
+    masks = O.philox_masks_for_net(seed, stream, row0, N, H, nh, pl) if mode == 1 else None
+    lo, mse, go, _, _ = O.nll_loss_and_grads(P, x, ds[1], pl, masks)
+    l = loss.cpu().numpy()
+    assert abs((l[0] + 0.01 * l[1]) / N - lo.item()) <= 2e-5 * abs(lo.item())
+    assert abs(l[2] / N - mse.item()) <= 2e-5 * abs(mse.item())
+    _check_grads(grads, go, H, nh, rtol=2e-4)
+    # and against the exact-fp32 kernels
+    g0, l0 = hh.train_grads(lib, H, nh, fp, xd, yd, drop, precision=0)
+    scale = float(g0.abs().max())
+    assert float((grads - g0).abs().max()) <= 2e-5 * scale
+    np.testing.assert_allclose(l[:3], l0.cpu().numpy()[:3], rtol=2e-6)
+
+
+def test_train_grads_x6_injected_masks(lib):
+    """G4 with the reference's recorded dropout masks through the x6 chain."""
+    import hip_helpers as hh
+    from conftest import load_golden, params_from_golden, unpack_mask
+    g = load_golden("g_net128.npz")
+    P = params_from_golden(g)
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"]).reshape(-1)
+    masks = [unpack_mask(g["mask%d_p0.2_t0" % l], 128 if l < 3 else 64) for l in range(4)]
+    bits = hh.pack_mask_bits([masks]).to(hh.dev())
+    drop = hh.dropout_struct(2, [0.2] * 4, bits=bits)
+    fp, xd, yd = hh.flat_params(P, 128, 3).to(hh.dev()), x.to(hh.dev()), y.to(hh.dev())
+    grads, loss = hh.train_grads(lib, 128, 3, fp, xd, yd, drop, precision=2)
+    N = x.shape[0]
+    l = loss.cpu().numpy()
+    total = l[0] / N + 0.01 * l[1] / N
+    assert abs(total - float(g["loss_p0.2_t0"])) <= 1e-5 * abs(float(g["loss_p0.2_t0"]))
+    _check_grads(grads, [g["grad." + n] for n in O.param_names(3)], 128, 3, rtol=1e-4)
