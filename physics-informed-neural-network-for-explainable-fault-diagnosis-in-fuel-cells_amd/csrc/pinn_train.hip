@@ -12,7 +12,9 @@
 //   grad_finalize_kernel : fixed-order sum of the slabs -> flat gradient (bitwise reproducible,
 //        no float atomics), already divided by the GLOBAL row count (data-parallel shards
 //        all-reduce it with SUM).
+#include <cstdlib>
 #include "pinn_mlp_core.h"
+#include "pinn_wgrad_args.h"
 
 namespace pinn {
 
@@ -222,21 +224,6 @@ __global__ __launch_bounds__(kThreads, 2) void train_chain_kernel(TrainArgs a) {
 // MFMA 32x32x2: k-step s of a 16-row tile pairs rows (s, s + 8): lane half hh supplies row 8*hh + s,
 // so a lane's operand for the 8 k-steps of a tile is 8 contiguous floats of one feature row.
 // ---------------------------------------------------------------------------------------
-struct WgradArgs {
-  const float* P;    // [T16][OUT][16]   d pre-activation of this layer
-  const float* Q;    // [T16][IN][16]    its input activation (or nullptr: read x rows, IN = 8)
-  const float* x;    // [n_rows][8] when Q == nullptr
-  long long n_rows;
-  int OUT, IN;
-  long long t16;
-  int n_slices;
-  long long slab_stride;    // floats between consecutive slices' slabs (= padded param count)
-  float* dW;                // slab of slice 0: [OUT][IN] row-major at the parameter's offset
-  float* db;                // slab of slice 0: [OUT]
-  const float* s1; float* dvq;                    // optional: dvq[j] = sum_rows s1[row] Q[j][row]
-  const float* s2; const float* R; float* dvr;    // optional: dvr[i] = sum_rows s2[row] R[i][row]
-};
-
 #define PINN_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 template <int TI, int TJ>
@@ -457,6 +444,17 @@ static int check_net_t(const pinn_net_t* net) {
   return PINN_OK;
 }
 
+// bf16 parts per operand of the PINN_PREC_F32X6 weight gradients: 2 (default; 3 products) or 3 (6 products,
+// fp32-equivalent) with PINN_WGRAD_PARTS=3 in the environment
+static int wgrad_parts() {
+  static int parts = 0;
+  if (parts == 0) {
+    const char* e = getenv("PINN_WGRAD_PARTS");
+    parts = (e && e[0] == '3') ? 3 : 2;
+  }
+  return parts;
+}
+
 static int cu_count() {
   static int cus = 0;
   if (cus == 0) {
@@ -498,6 +496,7 @@ int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const fl
                           long long n_global, const DropDev& drop, const TrainBuffers& b, int* grid_out, void* stream);   // pinn_x6_train.hip
 int launch_train_bf16(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y, long long n_rows,
                       long long n_global, const DropDev& drop, const TrainBuffers& b, unsigned phases, int* grid_out, void* stream);
+int dispatch_wgrad_x6(const WgradArgs& a, int ns, void* stream);   // pinn_x6_wgrad.hip
 }
 
 using namespace pinn;
@@ -603,18 +602,21 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     g.P = a.dpre_h; g.Q = nullptr; g.OUT = H; g.IN = 8; g.dW = slabs + L.w0(); g.db = slabs + L.b0();
     g.s1 = nullptr; g.dvq = nullptr; g.s2 = nullptr; g.R = nullptr; g.dvr = nullptr;
     if ((rc = dispatch_wgrad(g, st))) return rc;
+    // every layer but the input one: split-bf16 products on the matrix cores for PINN_PREC_F32X6
+    const int ns = net->precision == PINN_PREC_F32X6 ? wgrad_parts() : 0;
+    auto wgrad = [&](const WgradArgs& wa) { return ns ? dispatch_wgrad_x6(wa, ns, stream) : dispatch_wgrad(wa, st); };
     for (int l = 1; l < nh; ++l) {
       g.P = a.dpre_h + l * hs; g.Q = a.stash_h + (l - 1) * hs; g.OUT = H; g.IN = H; g.dW = slabs + L.w(l); g.db = slabs + L.b(l);
-      if ((rc = dispatch_wgrad(g, st))) return rc;
+      if ((rc = wgrad(g))) return rc;
     }
     // variance head layer 0 (+ predict weight: dw_p[j] = sum du * h_last[j])
     g.P = a.dpre_v1; g.Q = a.stash_h + (nh - 1) * hs; g.OUT = H / 2; g.IN = H; g.dW = slabs + L.wv0(); g.db = slabs + L.bv0();
     g.s1 = a.du; g.dvq = slabs + L.wp();
-    if ((rc = dispatch_wgrad(g, st))) return rc;
+    if ((rc = wgrad(g))) return rc;
     // variance head layer 1 (+ final weight: dwv2[i] = sum dz * v2[i])
     g.P = a.dpre_v2; g.Q = a.stash_v1; g.OUT = H / 4; g.IN = H / 2; g.dW = slabs + L.wv1(); g.db = slabs + L.bv1();
     g.s1 = nullptr; g.dvq = nullptr; g.s2 = a.dz; g.R = a.stash_v2; g.dvr = slabs + L.wv2();
-    if ((rc = dispatch_wgrad(g, st))) return rc;
+    if ((rc = wgrad(g))) return rc;
   }
 
   if (phases & PINN_PHASE_REDUCE)

@@ -1,0 +1,23 @@
+// pinn_wgrad_args.h -- arguments of the weight-gradient kernels (exact-fp32: pinn_train.hip; split-bf16: pinn_x6_wgrad.hip)
+#pragma once
+
+namespace pinn {
+
+// dW[i][j] = sum_rows P[i][row] Q[j][row]  (+ bias / vector sums), operands in the tiled stash layout
+struct WgradArgs {
+  const float* P;    // [T16][OUT][16]   d pre-activation of this layer
+  const float* Q;    // [T16][IN][16]    its input activation (or nullptr: read x rows, IN = 8)
+  const float* x;    // [n_rows][8] when Q == nullptr
+  long long n_rows;
+  int OUT, IN;
+  long long t16;
+  int n_slices;
+  long long slab_stride;    // floats between consecutive slices' slabs (= padded param count)
+  float* dW;                // slab of slice 0: [OUT][IN] row-major at the parameter's offset
+  float* db;                // slab of slice 0: [OUT]
+  const float* s1; float* dvq;                    // optional: dvq[j] = sum_rows s1[row] Q[j][row]
+  const float* s2; const float* R; float* dvr;    // optional: dvr[i] = sum_rows s2[row] R[i][row]
+};
+
+
+}  // namespace pinn

@@ -1,0 +1,198 @@
+// pinn_x6_wgrad.hip -- weight gradients on the bf16 matrix cores for PINN_PREC_F32X6.
+//
+// dW = dpre^T . h over K = rows, both operands read straight from the fp32 stash ([T16][F][16]: 8 contiguous rows
+// of one feature per lane = one v_mfma_f32_32x32x16_bf16 fragment), split in registers into bf16 parts
+// x = hi + mid (+ lo), and multiplied as
+//     NS = 2:  hi.hi + hi.mid + mid.hi                       (3 MFMAs per product)
+//     NS = 3:  ... + hi.lo + lo.hi + mid.mid                 (6 MFMAs, fp32-equivalent)
+// with fp32 accumulation.  NS = 2 drops terms of relative size 2^-16 per PRODUCT; they are zero-mean rounding
+// residues and the gradient is a sum over all rows, so the tensors come out ~5e-6 of their largest element from the
+// float64 result (torch's fp32 matmul: 3e-7; the parity tolerance on gradients: 2e-4) at half the NS = 3 cost.
+// Same slices / slabs / bias and vector-head sums as wgrad_kernel (pinn_train.hip); layer 0 (IN = 8) stays there.
+#include "pinn_x6_core.h"
+#include "pinn_wgrad_args.h"
+
+namespace pinn {
+namespace x6 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define PINN_MFMA32_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// 8 fp32 -> NS bf16x8 parts
+template <int NS>
+struct Parts {
+  u32x4 p[NS];
+};
+template <int NS>
+__device__ __forceinline__ Parts<NS> split8(const f32x4& v0, const f32x4& v1) {
+  Parts<NS> o;
+  float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bf16x2 h = {(__bf16)x[2 * q], (__bf16)x[2 * q + 1]};
+      o.p[s][q] = __builtin_bit_cast(unsigned, h);
+      if (s + 1 < NS) { x[2 * q] -= (float)h[0]; x[2 * q + 1] -= (float)h[1]; }
+    }
+  }
+  return o;
+}
+
+template <int TI, int TJ>
+struct Raw {
+  f32x4 a[TI][2], b[TJ][2];
+};
+template <int TI, int TJ>
+__device__ __forceinline__ void wgrad_load(Raw<TI, TJ>& f, const WgradArgs& a, long long t, int i0, int j0, int hh, int i) {
+  const float* pP = a.P + ((t * a.OUT + i0 + i) * 16 + 8 * hh);
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) {
+    f.a[ti][0] = *reinterpret_cast<const f32x4*>(pP + ti * 512);
+    f.a[ti][1] = *reinterpret_cast<const f32x4*>(pP + ti * 512 + 4);
+  }
+  const float* pQ = a.Q + ((t * a.IN + j0 + i) * 16 + 8 * hh);
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) {
+    f.b[tj][0] = *reinterpret_cast<const f32x4*>(pQ + tj * 512);
+    f.b[tj][1] = *reinterpret_cast<const f32x4*>(pQ + tj * 512 + 4);
+  }
+}
+
+template <int TI, int TJ, int WI, int WJ, int NS>
+__global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave >= WI * WJ) return;
+  const int wi = wave / WJ, wj = wave % WJ;
+  const int hh = lane >> 5, i = lane & 31;
+  const int i0 = wi * TI * 32, j0 = wj * TJ * 32;
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
+  float bsum[TI], vq[TJ], vr[TI];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) { bsum[ti] = 0.f; vr[ti] = 0.f; }
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) vq[tj] = 0.f;
+
+  const int slice = blockIdx.x;
+  const long long per = (a.t16 + a.n_slices - 1) / a.n_slices;
+  const long long t_begin = slice * per;
+  long long t_end = t_begin + per;
+  if (t_end > a.t16) t_end = a.t16;
+
+  // software pipeline: the fp32 fragments of tile t+1 are in flight while tile t is split and multiplied
+  Raw<TI, TJ> cur, nxt;
+  if (t_begin < t_end) wgrad_load<TI, TJ>(cur, a, t_begin, i0, j0, hh, i);
+  for (long long t = t_begin; t < t_end; ++t) {
+    const long long tn = (t + 1 < t_end) ? t + 1 : t;
+    wgrad_load<TI, TJ>(nxt, a, tn, i0, j0, hh, i);
+    Parts<NS> pa[TI], pb[TJ];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) pa[ti] = split8<NS>(cur.a[ti][0], cur.a[ti][1]);
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) pb[tj] = split8<NS>(cur.b[tj][0], cur.b[tj][1]);
+    // products (sa, sb) with sa + sb < NS, smallest first
+#pragma unroll
+    for (int tot = NS - 1; tot >= 0; --tot)
+#pragma unroll
+      for (int sa = 0; sa <= tot; ++sa)
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TJ; ++tj)
+            acc[ti][tj] = PINN_MFMA32_BF16(__builtin_bit_cast(bf16x8, pa[ti].p[sa]), __builtin_bit_cast(bf16x8, pb[tj].p[tot - sa]), acc[ti][tj]);
+    if (wj == 0) {
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) bsum[ti] += (cur.a[ti][sg][0] + cur.a[ti][sg][1]) + (cur.a[ti][sg][2] + cur.a[ti][sg][3]);
+      if (a.dvr) {
+        const float* pR = a.R + ((t * a.OUT + i0 + i) * 16 + 8 * hh);
+        const float* ps = a.s2 + t * 16 + 8 * hh;
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(ps + sg * 4);
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(pR + ti * 512 + sg * 4);
+            vr[ti] += (sv[0] * rv[0] + sv[1] * rv[1]) + (sv[2] * rv[2] + sv[3] * rv[3]);
+          }
+        }
+      }
+    }
+    if (wi == 0 && a.dvq) {
+      const float* ps = a.s1 + t * 16 + 8 * hh;
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg) {
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(ps + sg * 4);
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+          vq[tj] += (sv[0] * cur.b[tj][sg][0] + sv[1] * cur.b[tj][sg][1]) + (sv[2] * cur.b[tj][sg][2] + sv[3] * cur.b[tj][sg][3]);
+      }
+    }
+    cur = nxt;
+  }
+
+  // ---- write this slice's slab
+  const long long so = (long long)slice * a.slab_stride;
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const int col = j0 + tj * 32 + i;          // input feature (C/D layout: column on the lane)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        a.dW[so + (long long)row * a.IN + col] = acc[ti][tj][r];
+      }
+    }
+  if (wj == 0) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      const float b = bsum[ti] + __shfl_xor(bsum[ti], 32, 64);
+      if (hh == 0) a.db[so + i0 + ti * 32 + i] = b;
+      if (a.dvr) {
+        const float v = vr[ti] + __shfl_xor(vr[ti], 32, 64);
+        if (hh == 0) a.dvr[so + i0 + ti * 32 + i] = v;
+      }
+    }
+  }
+  if (wi == 0 && a.dvq) {
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const float v = vq[tj] + __shfl_xor(vq[tj], 32, 64);
+      if (hh == 0) a.dvq[so + j0 + tj * 32 + i] = v;
+    }
+  }
+}
+
+template <int TI, int TJ, int WI, int WJ>
+static void launch(const WgradArgs& a, int ns, hipStream_t st) {
+  if (ns == 3) hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, 3>), dim3(a.n_slices), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, 2>), dim3(a.n_slices), dim3(256), 0, st, a);
+}
+
+}  // namespace x6
+
+// [OUT x IN] gradient with IN a multiple of 32 (every layer but the input one); ns = bf16 parts per operand (2 or 3)
+int dispatch_wgrad_x6(const WgradArgs& a, int ns, void* stream) {
+  using namespace x6;
+  hipStream_t st = (hipStream_t)stream;
+  const int to = a.OUT / 32, ti = a.IN / 32;
+  if (a.Q == nullptr || a.IN % 32 || a.OUT % 32) return PINN_E_ARCH;
+  if (to == 8 && ti == 8) launch<4, 4, 2, 2>(a, ns, st);
+  else if (to == 4 && ti == 8) launch<2, 4, 2, 2>(a, ns, st);
+  else if (to == 2 && ti == 4) launch<1, 2, 2, 2>(a, ns, st);
+  else if (to == 4 && ti == 4) launch<2, 2, 2, 2>(a, ns, st);
+  else if (to == 1 && ti == 2) launch<1, 1, 1, 2>(a, ns, st);
+  else return PINN_E_ARCH;
+  return PINN_OK;
+}
+
+}  // namespace pinn

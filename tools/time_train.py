@@ -1,0 +1,32 @@
+"""Time the phases of pinn_mlp_train_grads at 1e6 rows: python tools/time_train.py [PREC ...]."""
+import ctypes, os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R, os.path.join(R, "tests"), os.path.join(R, "oracle")]
+import torch
+import pinn_amd
+from pinn_amd import _lib
+import hip_helpers as hh
+import pinn_oracle as O
+lib = _lib.load()
+H, nh, N = 256, 3, 1_000_000
+P = O.init_params([8, H, H, H, 1], seed=1)
+fp = hh.flat_params(P, H, nh).to(hh.dev())
+x = torch.rand(N, 8, device=hh.dev()); y = torch.rand(N, device=hh.dev())
+drop = hh.dropout_struct(1, [0.2] * 4, seed=1, stream_id=2)
+for prec in [int(a) for a in sys.argv[1:]] or [0, 1, 2]:
+    net = hh.make_net(lib, H, nh, prec)
+    wb = lib.pinn_train_workspace_bytes(ctypes.byref(net), N)
+    work = torch.empty(wb, dtype=torch.uint8, device=hh.dev())
+    grads = torch.empty(fp.numel(), device=hh.dev()); loss = torch.zeros(4, dtype=torch.float64, device=hh.dev())
+    def run(ph):
+        _lib.check(lib.pinn_mlp_train_grads_phases(ctypes.byref(net), hh.ptr(fp), hh.ptr(x), hh.ptr(y), N, N, ctypes.byref(drop), hh.ptr(grads),
+                                                   hh.ptr(loss), hh.ptr(work), wb, hh.stream(), ph), "train")
+    out = []
+    for ph in (1, 2, 4, 7):
+        for _ in range(2): run(ph)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): run(ph)
+        e1.record(); torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) / 5)
+    print("prec %d: chain %.3f ms  wgrad %.3f ms  reduce %.3f ms  all %.3f ms  (workspace %.2f GB)" % (prec, *out, wb / 1e9), flush=True)
