@@ -120,6 +120,8 @@ int pinn_lambda_step(int stage, const double* d_sums, long long n_global, float 
 #define PINN_PREC_FP32 0  /* exact fp32 matrix math (default; parity with the reference at fp32 tolerance) */
 #define PINN_PREC_BF16 1  /* bf16 MFMA inputs, fp32 accumulate / activations / loss / master weights   */
 #define PINN_PREC_F32X6 2 /* fp32-accurate on the bf16 matrix cores: 3-way bf16 split, 6 MFMAs per product */
+#define PINN_PREC_F32X6_G3 3 /* as F32X6, but the weight gradients split their operands in two bf16 parts (3 products):
+                                gradient tensors ~5e-6 of their largest element from float64 instead of ~3e-7 */
 
 typedef struct pinn_net {
   int n_in;       /* 8 */

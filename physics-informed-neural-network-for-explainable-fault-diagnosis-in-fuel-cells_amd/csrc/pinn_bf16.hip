@@ -560,6 +560,6 @@ extern "C" size_t pinn_packed_bytes(const pinn_net_t* net) {
   if (!net || net->n_in != 8 || (net->hidden != 128 && net->hidden != 256) || net->n_hidden < 1 || net->n_hidden > 8) return 0;
   PackLayout K{net->hidden, net->n_hidden};
   if (net->precision == PINN_PREC_BF16) return (size_t)K.total() * 2;
-  if (net->precision == PINN_PREC_F32X6) return (size_t)K.total() * 2 * 3;     // hi, mid, lo copies
+  if (net->precision == PINN_PREC_F32X6 || net->precision == PINN_PREC_F32X6_G3) return (size_t)K.total() * 2 * 3;     // hi, mid, lo copies
   return 0;
 }

@@ -106,7 +106,7 @@ static int check_net(const pinn_net_t* net) {
   if (net->n_in != 8) return PINN_E_ARCH;
   if (net->hidden != 128 && net->hidden != 256) return PINN_E_ARCH;
   if (net->n_hidden < 1 || net->n_hidden > 8) return PINN_E_ARCH;
-  if (net->precision < PINN_PREC_FP32 || net->precision > PINN_PREC_F32X6) return PINN_E_ARG;
+  if (net->precision < PINN_PREC_FP32 || net->precision > PINN_PREC_F32X6_G3) return PINN_E_ARG;
   if (net->precision != PINN_PREC_FP32 && !net->d_packed) return PINN_E_ARG;
   return PINN_OK;
 }
@@ -130,7 +130,7 @@ static int launch(const pinn_net_t* net, const FwdArgs& a, void* stream) {
   const long long n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
   if (n_tiles == 0) return PINN_OK;
   if (net->precision == PINN_PREC_BF16) return launch_forward_bf16(net, a, MC, stream);
-  if (net->precision == PINN_PREC_F32X6) return launch_forward_x6(net, a, MC, stream);
+  if (net->precision >= PINN_PREC_F32X6) return launch_forward_x6(net, a, MC, stream);
   const int grid = (int)(n_tiles < 2 * num_cus() ? n_tiles : 2 * num_cus());
   (void)hipGetLastError();   // drop a stale error left by another HIP user of this thread
   const bool bits = a.drop.mode == PINN_DROP_BITS;

@@ -413,7 +413,7 @@ static Workspace plan_workspace(const pinn_net_t* net, long long n_rows) {
   Workspace w;
   const long long H = net->hidden, nh = net->n_hidden;
   // whole workgroup tiles: 64 rows (4 wave tiles), 128 (8) for the x6 chain
-  w.t16 = net->precision == PINN_PREC_F32X6 ? (n_rows + 127) / 128 * 8 : (n_rows + kTileRows - 1) / kTileRows * 4;
+  w.t16 = net->precision >= PINN_PREC_F32X6 ? (n_rows + 127) / 128 * 8 : (n_rows + kTileRows - 1) / kTileRows * 4;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
   w.off_stash_h = take((size_t)nh * w.t16 * H * 16 * 4);
@@ -439,20 +439,9 @@ static int check_net_t(const pinn_net_t* net) {
   if (net->n_in != 8) return PINN_E_ARCH;
   if (net->hidden != 128 && net->hidden != 256) return PINN_E_ARCH;
   if (net->n_hidden < 1 || net->n_hidden > 8) return PINN_E_ARCH;
-  if (net->precision < PINN_PREC_FP32 || net->precision > PINN_PREC_F32X6) return PINN_E_ARG;
+  if (net->precision < PINN_PREC_FP32 || net->precision > PINN_PREC_F32X6_G3) return PINN_E_ARG;
   if (net->precision != PINN_PREC_FP32 && !net->d_packed) return PINN_E_ARG;
   return PINN_OK;
-}
-
-// bf16 parts per operand of the PINN_PREC_F32X6 weight gradients: 2 (default; 3 products) or 3 (6 products,
-// fp32-equivalent) with PINN_WGRAD_PARTS=3 in the environment
-static int wgrad_parts() {
-  static int parts = 0;
-  if (parts == 0) {
-    const char* e = getenv("PINN_WGRAD_PARTS");
-    parts = (e && e[0] == '3') ? 3 : 2;
-  }
-  return parts;
 }
 
 static int cu_count() {
@@ -568,7 +557,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     hipError_t eb = hipGetLastError();
     return eb == hipSuccess ? PINN_OK : (int)eb;
   }
-  if (net->precision == PINN_PREC_F32X6) {
+  if (net->precision >= PINN_PREC_F32X6) {
     // fp32-accurate chain on the bf16 matrix cores; the weight-gradient and finalize kernels below are shared
     if (phases & PINN_PHASE_CHAIN) {
       TrainBuffers b{};
@@ -603,7 +592,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     g.s1 = nullptr; g.dvq = nullptr; g.s2 = nullptr; g.R = nullptr; g.dvr = nullptr;
     if ((rc = dispatch_wgrad(g, st))) return rc;
     // every layer but the input one: split-bf16 products on the matrix cores for PINN_PREC_F32X6
-    const int ns = net->precision == PINN_PREC_F32X6 ? wgrad_parts() : 0;
+    const int ns = net->precision == PINN_PREC_F32X6 ? 3 : (net->precision == PINN_PREC_F32X6_G3 ? 2 : 0);   // bf16 parts per operand
     auto wgrad = [&](const WgradArgs& wa) { return ns ? dispatch_wgrad_x6(wa, ns, stream) : dispatch_wgrad(wa, st); };
     for (int l = 1; l < nh; ++l) {
       g.P = a.dpre_h + l * hs; g.Q = a.stash_h + (l - 1) * hs; g.OUT = H; g.IN = H; g.dW = slabs + L.w(l); g.db = slabs + L.b(l);

@@ -99,7 +99,9 @@ __global__ __launch_bounds__(kThreadsX, 2) void train_chain_x6_kernel(TrainArgsX
     }
 
     // ------------------------------------------------------------------ backward chain
+#ifndef PINN_X6_NOBWD
     backward_pass_x6<H>(small, L, pipe, a.drop, a.drop.mode, sx, ring, lane, du, dz, v2);
+#endif
   }
 
   // ---------------------------------------------------------------------- loss partial sums of this workgroup

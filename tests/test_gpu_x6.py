@@ -90,12 +90,14 @@ def _check_grads(got_flat, want_list, H, nh, rtol, atol_scale=1e-6):
         assert err <= rtol * scale + atol_scale * scale, (n, err, scale)
 
 
+@pytest.mark.parametrize("prec", [2, 3])
 @pytest.mark.parametrize("H,nh,N,mode", [(256, 3, 1000, 1), (128, 3, 333, 1), (256, 2, 129, 0), (128, 4, 4096, 1), (256, 1, 64, 1),
                                          (128, 1, 200, 1)])
-def test_train_grads_x6_vs_oracle_autograd(lib, H, nh, N, mode):
-    """Training step with the x6 chain (forward + NLL + backward; fp32 weight-gradient kernels on its stash): loss and
-    all 14 gradient tensors against torch autograd on the oracle -- the SAME tolerances as the exact-fp32 kernels
-    (tests/test_gpu_train.py)."""
+def test_train_grads_x6_vs_oracle_autograd(lib, H, nh, N, mode, prec):
+    """Training step with the x6 chain (forward + NLL + backward) and the split-bf16 weight-gradient kernels (prec 2:
+    three parts / six products; prec 3 = PINN_PREC_F32X6_G3: two parts / three products): loss and all 14 gradient
+    tensors against torch autograd on the oracle -- the SAME tolerances as the exact-fp32 kernels
+    (tests/test_gpu_train.py) -- and against those kernels."""
     import hip_helpers as hh
     from pinn_amd import synth
     P = O.init_params([8] + [H] * nh + [1], seed=H + nh)
@@ -105,7 +107,7 @@ def test_train_grads_x6_vs_oracle_autograd(lib, H, nh, N, mode):
     seed, stream, row0 = 987654321987, 42, 12345
     drop = hh.dropout_struct(mode, pl, seed=seed, stream_id=stream, row_offset=row0)
     fp, xd, yd = hh.flat_params(P, H, nh).to(hh.dev()), x.to(hh.dev()).contiguous(), y.to(hh.dev()).contiguous()
-    grads, loss = hh.train_grads(lib, H, nh, fp, xd, yd, drop, precision=2)
+    grads, loss = hh.train_grads(lib, H, nh, fp, xd, yd, drop, precision=prec)
     masks = O.philox_masks_for_net(seed, stream, row0, N, H, nh, pl) if mode == 1 else None
     lo, mse, go, _, _ = O.nll_loss_and_grads(P, x, ds[1], pl, masks)
     l = loss.cpu().numpy()
