@@ -6,7 +6,7 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Workload = BASELINE.json configs[1]: reference architecture [8,256,256,256,1] (p=0.2, variance
-head), ROWS_PER_GPU synthetic fuel-cell rows per GPU resident in HBM, fp32 (exact fp32 MFMA).
+head), ROWS_PER_GPU synthetic fuel-cell rows per GPU resident in HBM.
 One timed "step" advances EVERY trainer of the reference once over those rows:
    train_dnn step   : fused forward + aleatoric NLL + backward + weight gradients
                       + RCCL all-reduce(SUM) of the flat gradient bucket (N > 1) + Adam
@@ -15,11 +15,19 @@ One timed "step" advances EVERY trainer of the reference once over those rows:
                       (fused residual pass -> [all-reduce of 32 sums] -> Adam + clamp on device)
 value = rows of all ranks * steps / max-over-ranks wall time (weak scaling: rows per GPU fixed).
 
+Arithmetic (--precision, default f32x6 = the library default): fp32 in, fp32 out, fp32 accumulation;
+the matrix products run on the bf16 matrix cores with every operand split into three bf16 parts
+(hi + mid + lo = the fp32 value exactly) and six cross products -- the accuracy of an fp32 matmul
+(same parity tests and tolerances as the exact-fp32 kernels).  The exact-fp32 kernels
+(v_mfma_f32_*_f32) and the opt-in bf16-mixed ones are measured beside it ("exact_fp32",
+"bf16_mixed" objects) unless --only.
+
 Extra legs reported in the same JSON line (rank 0):
    mc_dropout   : get_MC_samples-equivalent launch (1 eval + T stochastic passes, on-chip reduce)
    roofline     : dominant kernel (forward+backward chain) timed alone with events on the launch
                   stream; algorithmic FLOP per row = 4*M - 4096 (forward 2M + dgrad 2(M - 8H)),
-                  M = 174 400 MAC, against the 157.3 TFLOP/s fp32-MFMA peak
+                  M = 174 400 MAC.  Peak: f32x6 executes 6 bf16 MFMA FLOP per algorithmic FLOP, so
+                  its ceiling is the dense bf16 peak / 6 = 416.7 TFLOP/s; exact fp32: 157.3 TFLOP/s.
    cpu_baseline : the CPU oracle's train_dnn step (torch CPU, autograd, torch-bernoulli masks,
                   Adam) on a bounded row sample, host cores of this box (N = 1 only)
 """
@@ -40,6 +48,17 @@ CHAIN_FLOP_PER_ROW = 4 * M_MAC - 2 * 2 * 8 * H                                 #
 STEP_FLOP_PER_ROW = 6 * M_MAC
 FWD_FLOP_PER_ROW = 2 * M_MAC
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+# per precision: (dtype string, chain kernel name, forward kernel name, peak in algorithmic TFLOP/s)
+PRECISIONS = {
+    "f32x6": ("f32 (products as 3x bf16-split operands, 6 bf16 MFMAs each, f32 accumulate: fp32-accurate)",
+              "train_chain_x6_kernel<256>", "mlp_x6_kernel<256,MC>", PEAK_BF16_MFMA_TFLOPS / 6.0),
+    "f32x6g3": ("f32 (as f32x6; weight gradients from 2 bf16 parts / 3 products)",
+                "train_chain_x6_kernel<256>", "mlp_x6_kernel<256,MC>", PEAK_BF16_MFMA_TFLOPS / 6.0),
+    "fp32": ("f32 (exact: v_mfma_f32_*_f32)", "train_chain_kernel<256>", "mlp_kernel<256,MC>", PEAK_FP32_MFMA_TFLOPS),
+    "bf16": ("bf16 MFMA inputs, f32 accumulate/activations/loss/master weights (parity rtol 2e-2)",
+             "train_chain_bf16_kernel<256>", "mlp_bf16_kernel<256,MC>", PEAK_BF16_MFMA_TFLOPS),
+}
 
 
 def parse():
@@ -52,6 +71,8 @@ def parse():
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=100_000)
+    ap.add_argument("--precision", default="f32x6", choices=sorted(PRECISIONS), help="arithmetic of the headline measurement")
+    ap.add_argument("--only", action="store_true", help="skip the extra legs in the other precisions")
     ap.add_argument("--no-bf16", action="store_true", help="skip the extra bf16/fp32-mixed leg")
     return ap.parse_args()
 
@@ -114,7 +135,7 @@ def main():
     y = torch.from_numpy(sy.transform(Up).astype("float32"))
     torch.manual_seed(0)                               # identical initial weights on every rank
     model = pinn_amd.PhysicsInformedNN(x, y, [8, H, H, H, 1], sx, sy, p=0.2, logvar=True, seed=0,
-                                       row_offset=rank * rows, n_global=n_global)
+                                       row_offset=rank * rows, n_global=n_global, precision=args.precision)
     model.verbose = False
     model.dnn.train()
     lib = model._lib
@@ -154,35 +175,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the eval forward that feeds net_f_V (weights frozen within a lambda stage: once per stage call)
-    model.dnn.eval(); u_eval.copy_(model.dnn(xd)[0].reshape(-1)); model.dnn.train()
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = n_global * args.steps / elapsed
-    final_loss = float((loss[0] + 0.01 * loss[1]).item() / n_global)
-
-    out = {
-        "metric": "pinn_train_samples_per_s", "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: %d synthetic rows x 8 features per GPU, PINN [8,256,256,256,1] + variance head, "
-                               "step = train_dnn (fwd+NLL+bwd+wgrad+allreduce+Adam) + one iteration of each of the 5 physics stages"
-                               % rows,
-                   "rows_per_gpu": rows, "global_rows": n_global, "parallelism": "dp%d" % world, "final_loss": final_loss},
-    }
-
-    # ------------------------------------------------------------------ roofline leg (rank 0 kernel, events on the launch stream)
     def time_events(fn, reps):
         fn(); torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -192,109 +184,111 @@ def main():
         ev1.record(); torch.cuda.synchronize()
         return ev0.elapsed_time(ev1) / reps     # ms
 
-    work = model._workspace(rows)
-    drop = model.dnn.dropout_struct(7, model.row_offset)
+    def max_over_ranks(seconds):
+        if world > 1:
+            t = torch.tensor([seconds], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return seconds
+
     loss_buf = torch.empty(4, dtype=torch.float64, device=dev)
 
-    def phase(ph):
-        return lambda: _lib.check(lib.pinn_mlp_train_grads_phases(
-            ctypes.byref(model.dnn._net), _ptr(flat), _ptr(xd), _ptr(yd), rows, n_global, ctypes.byref(drop), _ptr(model.dnn._flat_grad),
-            _ptr(loss_buf), _ptr(work), work.numel(), _stream(), ph), "phases")
-    reps = max(3, min(10, args.steps))
-    ms_chain = time_events(phase(1), reps)
-    ms_wgrad = time_events(phase(2), reps)
-    ms_reduce = time_events(phase(4), reps)
-    achieved = CHAIN_FLOP_PER_ROW * rows / (ms_chain * 1e-3) / 1e12
-    # HBM bytes per launch of the chain kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    # WRITE_SIZE collected in separate runs at this workload size); null when the row count differs
-    traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_summary_v2.json")
-    if rows == 1_000_000 and os.path.exists(pmc):
-        try:
-            k = [v for n, v in json.load(open(pmc)).items() if "train_chain_kernel" in n][0]
-            traffic = (k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
-            traffic_src = "profiles/r01/pmc_summary_v2.json: (FETCH_SIZE + WRITE_SIZE) KB x 1024, per launch, N=1e6; dword-per-lane " \
-                          "reads, so the 2x wide-read correction of FETCH_SIZE is not applied (uncalibrated, lower bound)"
-        except Exception:
-            pass
-    out["roofline"] = {"kernel": "train_chain_kernel<256>", "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                       "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                       "flop_per_row": CHAIN_FLOP_PER_ROW, "ms": ms_chain,
-                       "wgrad": {"ms": ms_wgrad, "achieved": FWD_FLOP_PER_ROW * rows / (ms_wgrad * 1e-3) / 1e12,
-                                 "frac": FWD_FLOP_PER_ROW * rows / (ms_wgrad * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
-                       "reduce_ms": ms_reduce,
-                       "step_mfma_frac": STEP_FLOP_PER_ROW * rows / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                       "hbm_algorithmic_GBps": 36.0 * rows / (ms_per_step * 1e-3) / 1e9}
-
-    # ------------------------------------------------------------------ MC-dropout leg
-    if not args.no_mc:
-        T = args.mc_passes
-        for m in model.dnn.dropout_modules():
-            m.p = 0.4
+    def measure(precision, warmup, steps):
+        """Timed steps, per-phase kernel times (events on the launch stream) and the MC-dropout launch in one precision."""
+        model.dnn.set_precision(precision)
+        dtype, chain_kernel, fwd_kernel, peak = PRECISIONS[precision]
         model.dnn.train()
-        model.mc_dropout(xd[:4096], 2); barrier()
-        t0 = time.perf_counter()
-        pm, au, eu = model.mc_dropout(xd, T, row_offset=model.row_offset)
-        barrier()
-        mc_s = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([mc_s], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            mc_s = float(t.item())
-        mc_tf = FWD_FLOP_PER_ROW * rows * (T + 1) / mc_s / 1e12
-        out["mc_dropout"] = {"metric": "mc_dropout_fwd_passes_per_s", "value": n_global * T / mc_s, "unit": "fwd-passes/s",
-                             "rows_per_gpu": rows, "passes": T, "seconds": mc_s,
-                             "roofline": {"kernel": "mlp_kernel<256,MC>", "bound": "mfma", "achieved": mc_tf, "peak": PEAK_FP32_MFMA_TFLOPS,
-                                          "unit": "TFLOP/s", "frac": mc_tf / PEAK_FP32_MFMA_TFLOPS,
-                                          "hbm_algorithmic_GBps": 44.0 * rows / mc_s / 1e9},
-                             "e_u_mean": float(eu.mean().item())}
-        for m in model.dnn.dropout_modules():
-            m.p = 0.2
-
-    # ------------------------------------------------------------------ extra leg: the same step and MC launch in bf16/fp32-mixed
-    if not args.no_bf16:
-        model.dnn.set_precision("bf16")
-        model.dnn.train()
-        for _ in range(max(1, args.warmup)):
+        for _ in range(warmup):
             one_step()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            one_step()
+        for _ in range(steps):
+            loss = one_step()
         barrier()
-        el = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        bf = {"dtype": "bf16 MFMA inputs, f32 accumulate/activations/loss/master weights (opt-in precision='bf16'; parity rtol 2e-2)",
-              "train_samples_per_s": n_global * args.steps / el, "ms_per_step": el / args.steps * 1e3}
-        drop_b = model.dnn.dropout_struct(7, model.row_offset)
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        r = {"precision": precision, "dtype": dtype, "elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3,
+             "train_samples_per_s": n_global * steps / elapsed, "final_loss": float((loss[0] + 0.01 * loss[1]).item() / n_global)}
+        work = model._workspace(rows)
+        drop = model.dnn.dropout_struct(7, model.row_offset)
 
-        def phase_b(ph):
+        def phase(ph):
             return lambda: _lib.check(lib.pinn_mlp_train_grads_phases(
-                ctypes.byref(model.dnn._net), _ptr(flat), _ptr(xd), _ptr(yd), rows, n_global, ctypes.byref(drop_b), _ptr(model.dnn._flat_grad),
+                ctypes.byref(model.dnn._net), _ptr(flat), _ptr(xd), _ptr(yd), rows, n_global, ctypes.byref(drop), _ptr(model.dnn._flat_grad),
                 _ptr(loss_buf), _ptr(work), work.numel(), _stream(), ph), "phases")
-        bf["chain_ms"], bf["wgrad_ms"] = time_events(phase_b(1), reps), time_events(phase_b(2), reps)
+        reps = max(3, min(10, steps))
+        ms_chain, ms_wgrad, ms_reduce = time_events(phase(1), reps), time_events(phase(2), reps), time_events(phase(4), reps)
+        achieved = CHAIN_FLOP_PER_ROW * rows / (ms_chain * 1e-3) / 1e12
+        wg = FWD_FLOP_PER_ROW * rows / (ms_wgrad * 1e-3) / 1e12
+        r["roofline"] = {"kernel": chain_kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "flop_per_row": CHAIN_FLOP_PER_ROW, "ms": ms_chain,
+                         "wgrad": {"ms": ms_wgrad, "achieved": wg, "frac": wg / (PEAK_BF16_MFMA_TFLOPS / 3.0 if precision == "f32x6g3" else peak)},
+                         "reduce_ms": ms_reduce,
+                         "step_mfma_frac": STEP_FLOP_PER_ROW * rows / (r["ms_per_step"] * 1e-3) / 1e12 / peak,
+                         "hbm_algorithmic_GBps": 36.0 * rows / (r["ms_per_step"] * 1e-3) / 1e9}
         if not args.no_mc:
             T = args.mc_passes
             for m in model.dnn.dropout_modules():
                 m.p = 0.4
+            model.dnn.train()
             model.mc_dropout(xd[:4096], 2); barrier()
             t0 = time.perf_counter()
-            model.mc_dropout(xd, T, row_offset=model.row_offset)
+            pm, au, eu = model.mc_dropout(xd, T, row_offset=model.row_offset)
             barrier()
-            mc_b = time.perf_counter() - t0
-            if world > 1:
-                t = torch.tensor([mc_b], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                mc_b = float(t.item())
-            bf["mc_fwd_passes_per_s"] = n_global * T / mc_b
-            bf["mc_seconds"] = mc_b
+            mc_s = max_over_ranks(time.perf_counter() - t0)
+            mc_tf = FWD_FLOP_PER_ROW * rows * (T + 1) / mc_s / 1e12
+            r["mc_dropout"] = {"metric": "mc_dropout_fwd_passes_per_s", "value": n_global * T / mc_s, "unit": "fwd-passes/s",
+                               "rows_per_gpu": rows, "passes": T, "seconds": mc_s,
+                               "roofline": {"kernel": fwd_kernel, "bound": "mfma", "achieved": mc_tf, "peak": peak, "unit": "TFLOP/s",
+                                            "frac": mc_tf / peak, "hbm_algorithmic_GBps": 44.0 * rows / mc_s / 1e9},
+                               "e_u_mean": float(eu.mean().item())}
             for m in model.dnn.dropout_modules():
                 m.p = 0.2
-        out["bf16_mixed"] = bf
-        model.dnn.set_precision("fp32")
+        return r
+
+    # the eval forward that feeds net_f_V (weights frozen within a lambda stage: once per stage call)
+    model.dnn.eval(); u_eval.copy_(model.dnn(xd)[0].reshape(-1)); model.dnn.train()
+    head = measure(args.precision, args.warmup, args.steps)
+    out = {
+        "metric": "pinn_train_samples_per_s", "value": head["train_samples_per_s"], "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": head["dtype"], "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: %d synthetic rows x 8 features per GPU, PINN [8,256,256,256,1] + variance head, "
+                               "step = train_dnn (fwd+NLL+bwd+wgrad+allreduce+Adam) + one iteration of each of the 5 physics stages"
+                               % rows,
+                   "rows_per_gpu": rows, "global_rows": n_global, "parallelism": "dp%d" % world, "precision": args.precision,
+                   "final_loss": head["final_loss"]},
+        "roofline": head["roofline"],
+    }
+    if "mc_dropout" in head:
+        out["mc_dropout"] = head["mc_dropout"]
+    # HBM bytes per launch of the chain kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
+    # in separate runs at this workload size); null when the row count or the kernel differs
+    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_summary_x6.json" if args.precision.startswith("f32x6") else "pmc_summary_v2.json")
+    if rows == 1_000_000 and os.path.exists(pmc):
+        try:
+            key = head["roofline"]["kernel"].split("<")[0]
+            k = [v for n, v in json.load(open(pmc)).items() if key in n][0]
+            out["roofline"]["traffic"] = (k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
+            out["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT) + ": (FETCH_SIZE + WRITE_SIZE) KB x 1024, per launch, N=1e6; " + \
+                k.get("note", "")
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ extra legs: the same measurement in the other precisions
+    if not args.only:
+        extras = [("exact_fp32", "fp32")] + ([] if args.no_bf16 else [("bf16_mixed", "bf16")])
+        for name, prec in extras:
+            if prec == args.precision:
+                continue
+            e = measure(prec, max(1, args.warmup), args.steps)
+            o = {"dtype": e["dtype"], "train_samples_per_s": e["train_samples_per_s"], "ms_per_step": e["ms_per_step"],
+                 "chain_ms": e["roofline"]["ms"], "chain_frac_of_peak": e["roofline"]["frac"], "peak_TFLOPs": e["roofline"]["peak"],
+                 "wgrad_ms": e["roofline"]["wgrad"]["ms"]}
+            if "mc_dropout" in e:
+                o["mc_fwd_passes_per_s"] = e["mc_dropout"]["value"]
+                o["mc_seconds"] = e["mc_dropout"]["seconds"]
+            out[name] = o
+        model.dnn.set_precision(args.precision)
 
     if rank == 0:
         if world == 1 and not args.no_cpu:
