@@ -1,0 +1,16 @@
+"""rocprofv3 counter_collection csvs -> {kernel: {counter: per-launch mean}} JSON: python tools/pmc_json.py DIR OUT.json"""
+import csv, glob, json, sys, collections
+d, out = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
+res = {}
+for k in sorted(acc):
+    if "pinn" not in k:
+        continue
+    res[k] = {(c + "_KB" if c in ("FETCH_SIZE", "WRITE_SIZE") else c): acc[k][c] / cnt[k][c] for c in sorted(acc[k])}
+    res[k]["launches"] = max(cnt[k].values())
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
