@@ -117,9 +117,11 @@ int pinn_lambda_step(int stage, const double* d_sums, long long n_global, float 
  *   W_0 b_0 ... W_{h-1} b_{h-1}  W_p b_p  Wv_0 bv_0  Wv_1 bv_1  Wv_2 bv_2
  * The fused kernels support hidden in {128, 256} (hidden % 128 == 0, <= 256), 1 <= n_hidden <= 8.
  */
-#define PINN_PREC_FP32 0  /* exact fp32 matrix math (default; parity with the reference at fp32 tolerance) */
-#define PINN_PREC_BF16 1  /* bf16 MFMA inputs, fp32 accumulate / activations / loss / master weights   */
-#define PINN_PREC_F32X6 2 /* fp32-accurate on the bf16 matrix cores: 3-way bf16 split, 6 MFMAs per product */
+#define PINN_PREC_FP32 0  /* exact fp32 matrix math (v_mfma_f32_*_f32); parity with the reference at fp32 tolerance */
+#define PINN_PREC_BF16 1  /* bf16 MFMA inputs, fp32 accumulate / activations / loss / master weights (rtol ~2e-2)    */
+#define PINN_PREC_F32X6 2 /* fp32-ACCURATE matrix math on the bf16 matrix cores: every operand split into three bf16
+                             parts, six MFMAs per product, fp32 accumulation; same tolerances as PINN_PREC_FP32, 1.3-2x
+                             faster.  What the Python surface uses by default. */
 #define PINN_PREC_F32X6_G3 3 /* as F32X6, but the weight gradients split their operands in two bf16 parts (3 products):
                                 gradient tensors ~5e-6 of their largest element from float64 instead of ~3e-7 */
 
@@ -128,7 +130,7 @@ typedef struct pinn_net {
   int hidden;     /* H */
   int n_hidden;   /* number of H-wide hidden layers (3 in the reference, 01:2139) */
   int precision;  /* PINN_PREC_* */
-  void* d_packed; /* PINN_PREC_BF16 / _F32X6 only: device scratch of pinn_packed_bytes(net) bytes; every call re-packs the
+  void* d_packed; /* every precision but PINN_PREC_FP32: device scratch of pinn_packed_bytes(net) bytes; every call re-packs the
                      bf16 weight copies from d_params into it (stateless), NULL for fp32 */
 } pinn_net_t;
 
