@@ -138,3 +138,47 @@ def test_train_grads_x6_injected_masks(lib):
     total = l[0] / N + 0.01 * l[1] / N
     assert abs(total - float(g["loss_p0.2_t0"])) <= 1e-5 * abs(float(g["loss_p0.2_t0"]))
     _check_grads(grads, [g["grad." + n] for n in O.param_names(3)], 128, 3, rtol=1e-4)
+
+
+def test_train_grads_x6_deterministic_and_shard_additive(lib):
+    """Size-independent properties through the x6 kernels: two identical calls are bitwise equal; two row shards with
+    n_global = N (Philox keyed by the global row) sum to the full-batch gradient."""
+    import hip_helpers as hh
+    from pinn_amd import synth
+    H, nh, N = 256, 3, 1536
+    P = O.init_params([8, H, H, H, 1], seed=3)
+    ds = synth.make_dataset(N, (), seed=9)
+    fp = hh.flat_params(P, H, nh).to(hh.dev())
+    x, y = ds[0].to(hh.dev()).contiguous(), ds[1].reshape(-1).to(hh.dev()).contiguous()
+    mk = lambda off: hh.dropout_struct(1, [0.2] * 4, seed=77, stream_id=5, row_offset=off)
+    g1, l1 = hh.train_grads(lib, H, nh, fp, x, y, mk(0), precision=2)
+    g2, l2 = hh.train_grads(lib, H, nh, fp, x, y, mk(0), precision=2)
+    assert torch.equal(g1, g2) and torch.equal(l1, l2)
+    cut = 640
+    ga, la = hh.train_grads(lib, H, nh, fp, x[:cut].contiguous(), y[:cut].contiguous(), mk(0), n_global=N, precision=2)
+    gb, lb = hh.train_grads(lib, H, nh, fp, x[cut:].contiguous(), y[cut:].contiguous(), mk(cut), n_global=N, precision=2)
+    scale = g1.abs().max().item()
+    assert (ga + gb - g1).abs().max().item() <= 2e-5 * scale
+    np.testing.assert_allclose((la + lb).cpu().numpy()[:3], l1.cpu().numpy()[:3], rtol=1e-6)
+
+
+def test_mc_dropout_x6_row_shards_match(lib):
+    """MC-dropout statistics of a row do not depend on which launch / shard holds it (row_offset keys the masks)."""
+    import hip_helpers as hh
+    from pinn_amd import _lib, synth
+    H, nh, N, T, p = 256, 3, 700, 8, 0.4
+    P = O.init_params([8, H, H, H, 1], seed=4)
+    x = synth.make_dataset(N, (), seed=6)[0].to(hh.dev()).contiguous()
+    fp = hh.flat_params(P, H, nh).to(hh.dev())
+    net = hh.make_net(lib, H, nh, 2)
+
+    def run(xs, off):
+        out = torch.empty(3, xs.shape[0], device=hh.dev())
+        d = hh.dropout_struct(1, [p] * 4, seed=5, stream_id=100, row_offset=off)
+        _lib.check(lib.pinn_mc_dropout(ctypes.byref(net), hh.ptr(fp), hh.ptr(xs), xs.shape[0], ctypes.byref(d), T, hh.ptr(out[0]), hh.ptr(out[1]),
+                                       hh.ptr(out[2]), hh.stream()), "mc")
+        torch.cuda.synchronize()
+        return out
+    full = run(x, 0)
+    a, b = run(x[:300].contiguous(), 0), run(x[300:].contiguous(), 300)
+    assert torch.equal(torch.cat([a, b], dim=1), full)
