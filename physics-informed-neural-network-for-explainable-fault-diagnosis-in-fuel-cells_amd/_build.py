@@ -22,6 +22,7 @@ SOURCES = [
     ("pinn_x6.hip", []),
     ("pinn_x6_train.hip", []),
     ("pinn_x6_wgrad.hip", []),
+    ("pinn_wide.hip", []),
     ("pinn_optim.hip", []),
 ]
 HEADERS = ["pinn_mlp_core.h", "pinn_bf16_core.h", "pinn_x6_core.h", "pinn_wgrad_args.h", os.path.join("..", "..", "include", "pinn_hip.h")]

@@ -556,9 +556,15 @@ int launch_train_bf16(const pinn_net_t* net, const float* d_params, const float*
 
 using namespace pinn;
 
+namespace pinn { size_t wide_scratch_floats(int H); }   // pinn_wide.hip
+
 extern "C" size_t pinn_packed_bytes(const pinn_net_t* net) {
-  if (!net || net->n_in != 8 || (net->hidden != 128 && net->hidden != 256) || net->n_hidden < 1 || net->n_hidden > 8) return 0;
+  if (!net || net->n_in != 8 || net->n_hidden < 1 || net->n_hidden > 8) return 0;
+  const bool wide = net->hidden == 512 || net->hidden == 1024 || net->hidden == 2048;
+  if (net->hidden != 128 && net->hidden != 256 && !wide) return 0;
   PackLayout K{net->hidden, net->n_hidden};
+  // wide nets: the three copies + the activation scratch of one row chunk (layer-by-layer kernels)
+  if (wide) return net->precision >= PINN_PREC_F32X6 ? (size_t)K.total() * 2 * 3 + pinn::wide_scratch_floats(net->hidden) * 4 : 0;
   if (net->precision == PINN_PREC_BF16) return (size_t)K.total() * 2;
   if (net->precision == PINN_PREC_F32X6 || net->precision == PINN_PREC_F32X6_G3) return (size_t)K.total() * 2 * 3;     // hi, mid, lo copies
   return 0;

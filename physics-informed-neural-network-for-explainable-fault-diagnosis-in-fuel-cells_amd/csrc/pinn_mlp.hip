@@ -104,9 +104,11 @@ static int convert_drop(const pinn_net_t* net, const pinn_dropout_t* in, DropDev
 static int check_net(const pinn_net_t* net) {
   if (!net) return PINN_E_ARG;
   if (net->n_in != 8) return PINN_E_ARCH;
-  if (net->hidden != 128 && net->hidden != 256) return PINN_E_ARCH;
+  const bool wide = net->hidden == 512 || net->hidden == 1024 || net->hidden == 2048;    // layer-by-layer kernels (pinn_wide.hip)
+  if (net->hidden != 128 && net->hidden != 256 && !wide) return PINN_E_ARCH;
   if (net->n_hidden < 1 || net->n_hidden > 8) return PINN_E_ARCH;
   if (net->precision < PINN_PREC_FP32 || net->precision > PINN_PREC_F32X6_G3) return PINN_E_ARG;
+  if (wide && net->precision < PINN_PREC_F32X6) return PINN_E_ARCH;                      // x6 arithmetic only
   if (net->precision != PINN_PREC_FP32 && !net->d_packed) return PINN_E_ARG;
   return PINN_OK;
 }
@@ -124,11 +126,13 @@ static int num_cus() {
 
 int launch_forward_bf16(const pinn_net_t* net, const FwdArgs& a, bool mc, void* stream);   // pinn_bf16.hip
 int launch_forward_x6(const pinn_net_t* net, const FwdArgs& a, bool mc, void* stream);     // pinn_x6.hip
+int launch_forward_wide(const pinn_net_t* net, const FwdArgs& a, bool mc, void* stream);   // pinn_wide.hip
 
 template <bool MC>
 static int launch(const pinn_net_t* net, const FwdArgs& a, void* stream) {
   const long long n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
   if (n_tiles == 0) return PINN_OK;
+  if (net->hidden > 256) return launch_forward_wide(net, a, MC, stream);
   if (net->precision == PINN_PREC_BF16) return launch_forward_bf16(net, a, MC, stream);
   if (net->precision >= PINN_PREC_F32X6) return launch_forward_x6(net, a, MC, stream);
   const int grid = (int)(n_tiles < 2 * num_cus() ? n_tiles : 2 * num_cus());

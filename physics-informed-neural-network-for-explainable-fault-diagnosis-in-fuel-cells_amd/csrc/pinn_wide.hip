@@ -1,0 +1,349 @@
+// pinn_wide.hip -- networks wider than the register-resident chain holds (hidden > 256, e.g. BASELINE config 5,
+// [8, 1024 x 4, 1]): layer-by-layer kernels on the same building blocks as the x6 chain (pinn_x6_core.h).
+//
+// Activations live in HBM between layers, in the stash layout [tile16][feature][16 rows] fp32 (scratch behind the
+// packed weights in pinn_net_t.d_packed; rows are processed in chunks of kWideChunk).  One layer kernel: a wave owns
+// 16 rows and computes 128 output features at a time (8 accumulator blocks); per 32-feature K-group the weight slab
+// (3 bf16 copies x 128 rows x 64 B) streams global -> LDS by LDS-DMA exactly as in the chain, and the B operand is
+// the input activation block (2 KB per wave and group), fetched by LDS-DMA two groups ahead into a per-wave ring and
+// split (hi, mid, lo) one group ahead, between the MFMA groups of the current slab.  Epilogue per 128 features:
+// bias is in the accumulator; tanh + Philox dropout (the same stream as every other kernel: keyed by global row,
+// layer, feature) -> next layer's input, or (backward) times the activation derivative -> d pre-activation.
+// fp32-accurate (PINN_PREC_F32X6 arithmetic); parity-tested, not tuned.
+#include "pinn_x6_core.h"
+
+namespace pinn {
+namespace wide {
+
+using namespace x6;
+
+constexpr int kWideChunk = 65536;        // rows per pass through the layer kernels (a multiple of 128)
+constexpr int kNT = 8;                   // 128 output features per accumulator set
+
+enum { EPI_TANH_DROP = 0, EPI_TANH = 1, EPI_BACKWARD = 2 };
+
+struct LayerArgs {
+  const float* params;       // flat fp32 parameters (biases, init weights)
+  const char* packed;        // three bf16 copies
+  unsigned copy_bytes;
+  const float* in;           // [T16][IN][16]
+  float* out;                // [T16][OUT][16]
+  const float* act;          // EPI_BACKWARD: post-dropout activation of the OUTPUT features, [T16][OUT][16]
+  const float* init_w;       // EPI_BACKWARD, optional: accumulator starts at init_w[f] * init_s[row]
+  const float* init_s;
+  long long n_rows, row_base;   // rows of this launch; global index of its first row (Philox) = drop.row_offset + chunk start
+  int IN, OUT;
+  unsigned mat_off;          // bf16-element offset of the [OUT][IN] matrix inside a copy
+  int kp_log;                // log2 of its row stride
+  long long bias_off;        // float offset of the bias in params (EPI_TANH*)
+  int layer;                 // dropout module index
+  DropDev drop;
+  unsigned pass;
+};
+
+// runtime-stride twin of Pipe6::piece
+__device__ __forceinline__ void piece_rt(Pipe6& pipe, unsigned off, int kp_log, int nrb_log, int j, int buf) {
+  int p = pipe.wave + 8 * j;
+  const int n = 3 << nrb_log;
+  p = p < n ? p : p - n;
+  asm volatile("" : "+s"(p));
+  const unsigned voff = ((pipe.lane_row << kp_log) << 1) + pipe.lane_kq8;
+  const int copy = p >> nrb_log, rb = p & ((1 << nrb_log) - 1);
+  const unsigned long long goff = (unsigned long long)copy * pipe.copy_bytes + 2ull * (off + ((unsigned)(rb * 16) << kp_log));
+  char* dst = pipe.lds + buf * kSlabBytes + copy * (kSlabBytes / 3) + rb * 1024;
+  __builtin_amdgcn_global_load_lds((gptr_t)(pipe.packed + goff + voff), (lptr_t)dst, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a) {
+  constexpr int kRingBytes = 8 * 2 * 2048;
+  constexpr int kSlabAt = (kRingBytes + 1023) & ~1023;
+  __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * kSlabBytes];
+  Pipe6 pipe;
+  pipe.packed = a.packed; pipe.copy_bytes = a.copy_bytes; pipe.lds = smem + kSlabAt;
+  pipe.init(threadIdx.x);
+  const int lane = threadIdx.x & 63, wave = pipe.wave, kq = lane >> 4;
+  const StashRing ring{smem + wave * 4096, lane};
+  const int NG = a.IN / 32, nob = a.OUT / 128;
+  auto slab_off = [&](int ob, int g) { return a.mat_off + ((unsigned)(ob * 128) << a.kp_log) + 32u * (unsigned)g; };
+  // slab (0, 0)
+  pipe.par = 0;
+  for (int j = 0; j < 3; ++j) piece_rt(pipe, slab_off(0, 0), a.kp_log, 3, j, 0);
+  __syncthreads();
+
+  const long long n_tiles = (a.n_rows + kTileRowsX - 1) / kTileRowsX;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long t16 = tile * 8 + wave;
+    const long long lrow = t16 * 16 + (lane & 15);
+    const bool valid = lrow < a.n_rows;
+    const RowCtx c{lane, kq, a.row_base + lrow, lrow, a.n_rows, a.pass, a.drop.mode};
+    const float* in_tile = a.in + t16 * a.IN * 16;
+    auto fetch = [&](int g) { ring.fetch(in_tile + 32 * g * 16, g & 1); };
+    // blocks 0 and 1 of this tile's input; block 0 is split at once (nothing to hide it under)
+    fetch(0);
+    fetch(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Prep st;
+    Frag3 cur;
+    static_for<4>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      split_pair<r>(ring.read(0, 0, r), ring.read(0, 1, r), cur);
+    });
+#pragma unroll 1
+    for (int ob = 0; ob < nob; ++ob) {
+      f32x4 acc[kNT];
+      if (EPI == EPI_BACKWARD) {
+        const float s = a.init_w ? a.init_s[valid ? lrow : a.n_rows - 1] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+          const f32x4 w = a.init_w ? *reinterpret_cast<const f32x4*>(a.init_w + ob * 128 + t * 16 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[t] = w * s;
+        }
+      } else {
+        bias_blocks<kNT>(acc, a.params + a.bias_off + ob * 128, kq);
+      }
+#pragma unroll 1
+      for (int g = 0; g < NG; ++g) {
+        // next slab, next block to split (g + 1), block to fetch (g + 2); the input blocks repeat for every ob
+        const bool last_g = g + 1 == NG;
+        const int ob2 = last_g ? (ob + 1 < nob ? ob + 1 : 0) : ob, g2 = last_g ? 0 : g + 1;
+        const unsigned off2 = slab_off(ob2, g2);
+        const int gb = g2, gf = g + 2 < NG ? g + 2 : g + 2 - NG;
+        auto dma = [&](auto slotc) {
+          constexpr int slot = decltype(slotc)::value;
+          if constexpr (slot < 3) piece_rt(pipe, off2, a.kp_log, 3, slot, pipe.par ^ 1);
+          if constexpr (slot == 3) fetch(gf);
+        };
+        auto vchunk = [&](auto cc) {
+          constexpr int ci = decltype(cc)::value;
+          if constexpr (ci % 2 == 1) {
+            constexpr int r = ci / 2;
+            split_pair<r>(ring.read(gb & 1, 0, r), ring.read(gb & 1, 1, r), st.out);
+          }
+        };
+        slab_mfma<kNT>(acc, cur, pipe.cur(), lane, vchunk, dma);
+        pipe.advance();
+        cur = st.out;
+      }
+      // ---- epilogue of these 128 output features
+      float* out_tile = a.out + (t16 * a.OUT + ob * 128 + 4 * kq) * 16 + (lane & 15);
+      if (EPI == EPI_BACKWARD) {
+        const float scale = a.drop.mode != PINN_DROP_NONE ? a.drop.scale[a.layer] : 1.0f, inv_scale = 1.0f / scale;
+        const float* hp = a.act + (t16 * a.OUT + ob * 128 + 4 * kq) * 16 + (lane & 15);
+        f32x4 hl[kNT];
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) load_block(hp, t, hl[t]);
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float av = hl[t][r] * inv_scale;
+            const float gv = acc[t][r] * (scale * (1.0f - av * av));
+            acc[t][r] = hl[t][r] != 0.0f ? gv : 0.0f;
+          }
+          store_block(out_tile, t, acc[t]);
+        }
+      } else if (EPI == EPI_TANH_DROP) {
+        const LayerDrop ldr = layer_drop(a.drop, c.mode, a.layer);
+#pragma unroll
+        for (int k = 0; k < kNT / 2; ++k) {
+          const unsigned keep = activate_pair<false>(acc[2 * k], acc[2 * k + 1], a.drop, c, ldr, a.layer, ob * 4 + k);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[2 * k][r] = stash_value(acc[2 * k][r], (keep >> r) & 1u);
+            acc[2 * k + 1][r] = stash_value(acc[2 * k + 1][r], (keep >> (4 + r)) & 1u);
+          }
+          store_block(out_tile, 2 * k, acc[2 * k]);
+          store_block(out_tile, 2 * k + 1, acc[2 * k + 1]);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+          activate_tanh(acc[t]);
+          store_block(out_tile, t, acc[t]);
+        }
+      }
+    }
+  }
+}
+
+// input layer: h0 = dropout(tanh(W0 x + b0)) -> stash; 8 MACs per output, VALU
+struct InputArgs {
+  const float* params;
+  const float* x;
+  float* out;               // [T16][H][16]
+  long long n_rows, row_base;
+  int H;
+  long long w0_off, b0_off;
+  DropDev drop;
+  unsigned pass;
+};
+__global__ __launch_bounds__(256) void wide_input_kernel(InputArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane >> 4;
+  const long long n_t16 = (a.n_rows + 127) / 128 * 8;
+  const LayerDrop ldr = layer_drop(a.drop, a.drop.mode, 0);
+  for (long long t16 = (long long)blockIdx.x * 4 + wave; t16 < n_t16; t16 += (long long)gridDim.x * 4) {
+    const long long lrow = t16 * 16 + (lane & 15);
+    const long long srow = lrow < a.n_rows ? lrow : a.n_rows - 1;
+    const f32x4 xa = reinterpret_cast<const f32x4*>(a.x)[srow * 2], xb = reinterpret_cast<const f32x4*>(a.x)[srow * 2 + 1];
+    const RowCtx c{lane, kq, a.row_base + lrow, lrow, a.n_rows, a.pass, a.drop.mode};
+    float* out_tile = a.out + (t16 * a.H + 4 * kq) * 16 + (lane & 15);
+    for (int fp = 0; fp < a.H / 32; ++fp) {
+      f32x4 v[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 32 * fp + 16 * b + 4 * kq + r;
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.params + a.w0_off + f * 8);
+          const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.params + a.w0_off + f * 8 + 4);
+          float s = a.params[a.b0_off + f];
+          // the k order of the fused kernels' input MFMA (k-step t contracts inputs {t, 4 + t}) is immaterial here: plain fp32 FMAs
+          s = fmaf(w0[0], xa[0], s); s = fmaf(w0[1], xa[1], s); s = fmaf(w0[2], xa[2], s); s = fmaf(w0[3], xa[3], s);
+          s = fmaf(w1[0], xb[0], s); s = fmaf(w1[1], xb[1], s); s = fmaf(w1[2], xb[2], s); s = fmaf(w1[3], xb[3], s);
+          v[b][r] = s;
+        }
+      const unsigned keep = activate_pair<false>(v[0], v[1], a.drop, c, ldr, 0, fp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[0][r] = stash_value(v[0][r], (keep >> r) & 1u);
+        v[1][r] = stash_value(v[1][r], (keep >> (4 + r)) & 1u);
+      }
+      store_block(out_tile, 2 * fp, v[0]);
+      store_block(out_tile, 2 * fp + 1, v[1]);
+    }
+  }
+}
+
+// heads: u = w_p . h_last + b_p, z = wv_2 . v2 + bv_2, logvar = log(softplus(z) + 1e-6)
+//   mode 0: write (u, logvar);  1: MC eval pass (pred_mean = u, reset the sums);  2: MC stochastic pass (accumulate)
+struct HeadArgs {
+  const float* params;
+  const float* h;           // [T16][H][16]
+  const float* v2;          // [T16][H/4][16]
+  long long n_rows;
+  int H;
+  long long wp_off, bp_off, wv2_off, bv2_off;
+  int mode;
+  float* o0; float* o1;     // mode 0: u, logvar; mode 1: pred_mean
+  float* accum;             // modes 1, 2: [4][chunk rows]: u_eval, sum du, sum du^2, sum logvar
+  long long accum_stride;
+};
+__global__ __launch_bounds__(256) void wide_heads_kernel(HeadArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane >> 4;
+  const long long n_t16 = (a.n_rows + 127) / 128 * 8;
+  for (long long t16 = (long long)blockIdx.x * 4 + wave; t16 < n_t16; t16 += (long long)gridDim.x * 4) {
+    const long long lrow = t16 * 16 + (lane & 15);
+    const float* hp = a.h + (t16 * a.H + 4 * kq) * 16 + (lane & 15);
+    const float* vp = a.v2 + (t16 * (a.H / 4) + 4 * kq) * 16 + (lane & 15);
+    float up = 0.f, zp = 0.f;
+    for (int t = 0; t < a.H / 16; ++t) {
+      f32x4 hv;
+      load_block(hp, t, hv);
+      up = block_dot(hv, a.params + a.wp_off + t * 16, kq, up);
+    }
+    for (int t = 0; t < a.H / 64; ++t) {
+      f32x4 vv;
+      load_block(vp, t, vv);
+      zp = block_dot(vv, a.params + a.wv2_off + t * 16, kq, zp);
+    }
+    const float u = sum_kq(up) + a.params[a.bp_off], z = sum_kq(zp) + a.params[a.bv2_off];
+    const float lv = logf(softplus_f32(z) + 1e-6f);
+    if (lrow < a.n_rows && lane < 16) {
+      if (a.mode == 0) { a.o0[lrow] = u; a.o1[lrow] = lv; }
+      else if (a.mode == 1) {
+        a.o0[lrow] = u;
+        a.accum[lrow] = u; a.accum[a.accum_stride + lrow] = 0.f; a.accum[2 * a.accum_stride + lrow] = 0.f; a.accum[3 * a.accum_stride + lrow] = 0.f;
+      } else {
+        const float du = u - a.accum[lrow];
+        a.accum[a.accum_stride + lrow] += du;
+        a.accum[2 * a.accum_stride + lrow] += du * du;
+        a.accum[3 * a.accum_stride + lrow] += lv;
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void wide_mc_finalize_kernel(const float* accum, long long stride, long long n, int n_passes, float* a_u, float* e_u) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float inv_t = 1.0f / (float)n_passes;
+  const float m = accum[stride + i] * inv_t;
+  const float var = fmaxf(accum[2 * stride + i] * inv_t - m * m, 0.0f);
+  a_u[i] = expf(0.5f * (accum[3 * stride + i] * inv_t));
+  e_u[i] = sqrtf(var);
+}
+
+}  // namespace wide
+
+namespace x6 {
+void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st);   // pinn_x6.hip
+}
+
+// scratch behind the packed weights (floats): two activation buffers, v1, v2, the MC sums
+size_t wide_scratch_floats(int H) {
+  return (size_t)wide::kWideChunk * (2 * (size_t)H + H / 2 + H / 4 + 4);
+}
+
+static int wide_cus() {
+  int cus = 0, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  return cus > 0 ? cus : 256;
+}
+
+// forward / MC-dropout of a wide net: chunks of rows through input -> hidden layers -> variance head -> heads
+int launch_forward_wide(const pinn_net_t* net, const FwdArgs& fa, bool mc, void* stream) {
+  using namespace wide;
+  hipStream_t st = (hipStream_t)stream;
+  const int H = net->hidden, nh = net->n_hidden;
+  if (fa.drop.mode == PINN_DROP_BITS) return PINN_E_ARCH;       // injected masks: fused kernels only
+  ParamLayout L{H, nh};
+  PackLayout K{H, nh};
+  x6::launch_pack_x6(net, fa.params, st);
+  const char* packed = (const char*)net->d_packed;
+  const unsigned copy_bytes = (unsigned)(K.total() * 2);
+  float* scratch = (float*)((char*)net->d_packed + (size_t)K.total() * 2 * 3);
+  float* bufA = scratch; float* bufB = bufA + (size_t)kWideChunk * H;
+  float* v1 = bufB + (size_t)kWideChunk * H; float* v2 = v1 + (size_t)kWideChunk * (H / 2);
+  float* accum = v2 + (size_t)kWideChunk * (H / 4);
+  const int cus = wide_cus();
+  const int n_passes = mc ? fa.n_passes : 0;
+  for (long long r0 = 0; r0 < fa.n_rows; r0 += kWideChunk) {
+    const long long n = fa.n_rows - r0 < kWideChunk ? fa.n_rows - r0 : kWideChunk;
+    const long long tiles = (n + 127) / 128;
+    const int grid_l = (int)(tiles < cus ? tiles : cus), grid_s = (int)((tiles * 2 < 4 * cus) ? tiles * 2 : 4 * cus);
+    for (int pass = -1; pass < n_passes; ++pass) {
+      DropDev d = fa.drop;
+      const bool stochastic = mc ? pass >= 0 : fa.drop.mode != PINN_DROP_NONE;
+      if (!stochastic) d.mode = PINN_DROP_NONE;
+      const unsigned p = pass < 0 ? 0u : (unsigned)pass;
+      InputArgs ia{fa.params, fa.x + r0 * 8, bufA, n, d.row_offset + r0, H, L.w0(), L.b0(), d, p};
+      hipLaunchKernelGGL(wide_input_kernel, dim3(grid_s), dim3(256), 0, st, ia);
+      float* cur = bufA; float* nxt = bufB;
+      LayerArgs la{};
+      la.params = fa.params; la.packed = packed; la.copy_bytes = copy_bytes; la.n_rows = n; la.row_base = d.row_offset + r0; la.drop = d; la.pass = p;
+      for (int l = 1; l < nh; ++l) {
+        la.in = cur; la.out = nxt; la.IN = H; la.OUT = H; la.mat_off = (unsigned)K.w(l); la.kp_log = 31 - __builtin_clz((unsigned)H);
+        la.bias_off = L.b(l); la.layer = l;
+        hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_TANH_DROP>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+        float* t = cur; cur = nxt; nxt = t;
+      }
+      la.in = cur; la.out = v1; la.IN = H; la.OUT = H / 2; la.mat_off = (unsigned)K.wv0(); la.kp_log = 31 - __builtin_clz((unsigned)H);
+      la.bias_off = L.bv0(); la.layer = nh;
+      hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_TANH_DROP>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+      la.in = v1; la.out = v2; la.IN = H / 2; la.OUT = H / 4; la.mat_off = (unsigned)K.wv1(); la.kp_log = 31 - __builtin_clz((unsigned)round_up64(H / 2));
+      la.bias_off = L.bv1(); la.layer = nh + 1;
+      hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_TANH>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+      HeadArgs ha{fa.params, cur, v2, n, H, L.wp(), L.bp(), L.wv2(), L.bv2(), mc ? (pass < 0 ? 1 : 2) : 0,
+                  fa.o0 + r0, mc ? nullptr : fa.o1 + r0, accum, kWideChunk};
+      hipLaunchKernelGGL(wide_heads_kernel, dim3(grid_s), dim3(256), 0, st, ha);
+      if (!mc) break;
+    }
+    if (mc) hipLaunchKernelGGL(wide_mc_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, accum, (long long)kWideChunk, n, n_passes,
+                               fa.o1 + r0, fa.o2 + r0);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PINN_OK : (int)e;
+}
+
+}  // namespace pinn

@@ -182,3 +182,44 @@ def test_mc_dropout_x6_row_shards_match(lib):
     full = run(x, 0)
     a, b = run(x[:300].contiguous(), 0), run(x[300:].contiguous(), 300)
     assert torch.equal(torch.cat([a, b], dim=1), full)
+
+
+@pytest.mark.parametrize("H,nh,N,mode", [(512, 2, 300, 1), (1024, 4, 200, 1), (1024, 4, 129, 0), (512, 1, 64, 1)])
+def test_forward_wide(lib, H, nh, N, mode):
+    """Nets wider than the register-resident chain (BASELINE config 5 = [8, 1024 x 4, 1]): the layer-by-layer kernels
+    of pinn_wide.hip against the fp32 oracle, same Philox stream, fp32 tolerance."""
+    import hip_helpers as hh
+    from pinn_amd import synth
+    P = O.init_params([8] + [H] * nh + [1], seed=H + nh)
+    x = synth.make_dataset(max(N, 2), (), seed=N)[0][:N].contiguous()
+    fp, xd = hh.flat_params(P, H, nh).to(hh.dev()), x.to(hh.dev())
+    pl = [0.2] * (nh + 1)
+    seed, stream, row0 = 424242, 9, 1000
+    drop = hh.dropout_struct(mode, pl, seed=seed, stream_id=stream, row_offset=row0)
+    u, lv = hh.forward(lib, H, nh, fp, xd, drop, precision=2)
+    masks = O.philox_masks_for_net(seed, stream, row0, N, H, nh, pl) if mode else None
+    with torch.no_grad():
+        uf, lvf = O.mlp_forward(P, x, pl, masks)
+    np.testing.assert_allclose(u.cpu().numpy(), uf.numpy().reshape(-1), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lv.cpu().numpy(), lvf.numpy().reshape(-1), rtol=1e-5, atol=1e-5)
+
+
+def test_mc_dropout_wide(lib):
+    import hip_helpers as hh
+    from pinn_amd import _lib, synth
+    H, nh, N, T, p = 1024, 4, 150, 6, 0.4
+    P = O.init_params([8] + [H] * nh + [1], seed=1)
+    x = synth.make_dataset(N, (), seed=2)[0]
+    out = torch.empty(3, N, device=hh.dev())
+    net = hh.make_net(lib, H, nh, 2)
+    pl = [p] * (nh + 1)
+    d = hh.dropout_struct(1, pl, seed=99, stream_id=1000, row_offset=0)
+    fp, xd = hh.flat_params(P, H, nh).to(hh.dev()), x.to(hh.dev())
+    _lib.check(lib.pinn_mc_dropout(ctypes.byref(net), hh.ptr(fp), hh.ptr(xd), N, ctypes.byref(d), T, hh.ptr(out[0]), hh.ptr(out[1]),
+                                   hh.ptr(out[2]), hh.stream()), "mc")
+    o = out.cpu().numpy()
+    mf = lambda t: O.philox_masks_for_net(99, 1000 + t, 0, N, H, nh, pl)
+    pm, au, eu = O.mc_dropout(P, x, p, T, mf)
+    np.testing.assert_allclose(o[0], np.asarray(pm).reshape(-1), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(o[1], np.asarray(au).reshape(-1), rtol=1e-4)
+    np.testing.assert_allclose(o[2], np.asarray(eu).reshape(-1), rtol=1e-3, atol=1e-5)

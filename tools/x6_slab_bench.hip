@@ -49,8 +49,11 @@ int main() {
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
       }
-      printf("dma %d, %d waves/SIMD: wave 0 sees %.0f ticks per slab; wall %.3f ms = %.0f ns per slab step (MFMA-bound: %.0f ns at 2.4 GHz)\n", dma, threads / 256,
+      printf("dma %d, %d waves/SIMD: wave 0 sees %.0f ticks per slab; wall %.3f ms = %.0f ns per slab step (MFMA-bound: %.0f ns at 2.4 GHz)", dma, threads / 256,
              (double)h / iters, ms, ms * 1e6 / iters, 1536.0 * threads / 256 / 2.4);
+      // with a barrier per slab (dma = 1) or one wave per SIMD, wave 0 spans the whole kernel: ticks / wall = shader clock
+      if (dma || threads == 256) printf("  -> shader clock %.2f GHz", (double)h / (ms * 1e6));
+      printf("\n");
     }
   return 0;
 }
