@@ -154,7 +154,10 @@ static int launch(const pinn_net_t* net, const FwdArgs& a, void* stream) {
 using namespace pinn;
 
 extern "C" long long pinn_param_count(const pinn_net_t* net) {
-  if (check_net(net) != PINN_OK) return check_net(net);
+  // the shape alone decides (precision / d_packed are not needed to size the parameter buffer)
+  if (!net) return PINN_E_ARG;
+  const bool wide = net->hidden == 512 || net->hidden == 1024 || net->hidden == 2048;
+  if (net->n_in != 8 || (net->hidden != 128 && net->hidden != 256 && !wide) || net->n_hidden < 1 || net->n_hidden > 8) return PINN_E_ARCH;
   ParamLayout L{net->hidden, net->n_hidden};
   return L.total();
 }

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
   if (wave >= WI * WJ) return;
   const int wi = wave / WJ, wj = wave % WJ;
   const int hh = lane >> 5, i = lane & 31;
-  const int i0 = wi * TI * 32, j0 = wj * TJ * 32;
+  const int i0 = blockIdx.y * (TI * 32 * WI) + wi * TI * 32, j0 = wj * TJ * 32;     // blockIdx.y: output block (wide nets' layer 0)
 
   f32x16 acc[TI][TJ];
 #pragma unroll
@@ -437,9 +437,11 @@ static Workspace plan_workspace(const pinn_net_t* net, long long n_rows) {
 static int check_net_t(const pinn_net_t* net) {
   if (!net) return PINN_E_ARG;
   if (net->n_in != 8) return PINN_E_ARCH;
-  if (net->hidden != 128 && net->hidden != 256) return PINN_E_ARCH;
+  const bool wide = net->hidden == 512 || net->hidden == 1024 || net->hidden == 2048;    // layer-by-layer kernels (pinn_wide.hip)
+  if (net->hidden != 128 && net->hidden != 256 && !wide) return PINN_E_ARCH;
   if (net->n_hidden < 1 || net->n_hidden > 8) return PINN_E_ARCH;
   if (net->precision < PINN_PREC_FP32 || net->precision > PINN_PREC_F32X6_G3) return PINN_E_ARG;
+  if (wide && net->precision < PINN_PREC_F32X6) return PINN_E_ARCH;
   if (net->precision != PINN_PREC_FP32 && !net->d_packed) return PINN_E_ARG;
   return PINN_OK;
 }
@@ -456,15 +458,15 @@ static int cu_count() {
 }
 
 template <int TI, int TJ, int WI, int WJ, bool QX>
-static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, QX>), dim3(a.n_slices), dim3(kThreads), 0, st, a);
+static void launch_wgrad(const WgradArgs& a, hipStream_t st, int out_blocks = 1) {
+  hipLaunchKernelGGL((wgrad_kernel<TI, TJ, WI, WJ, QX>), dim3(a.n_slices, out_blocks), dim3(kThreads), 0, st, a);
 }
 
 // pick the wave tiling for an [OUT x IN] gradient (tiles of 32x32; IN = 8 is padded to one tile)
 static int dispatch_wgrad(const WgradArgs& a, hipStream_t st) {
   const int to = a.OUT / 32, ti = (a.IN + 31) / 32;
   if (a.Q == nullptr) {
-    if (to == 8) launch_wgrad<2, 1, 4, 1, true>(a, st);
+    if (to % 8 == 0) launch_wgrad<2, 1, 4, 1, true>(a, st, to / 8);       // 256 outputs per workgroup
     else if (to == 4) launch_wgrad<1, 1, 4, 1, true>(a, st);
     else return PINN_E_ARCH;
     return PINN_OK;
@@ -483,6 +485,8 @@ static int dispatch_wgrad(const WgradArgs& a, hipStream_t st) {
 namespace pinn {
 int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y, long long n_rows,
                           long long n_global, const DropDev& drop, const TrainBuffers& b, int* grid_out, void* stream);   // pinn_x6_train.hip
+int launch_train_chain_wide(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y, long long n_rows,
+                            long long n_global, const DropDev& drop, const TrainBuffers& b, int* grid_out, void* stream);  // pinn_wide.hip
 int launch_train_bf16(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y, long long n_rows,
                       long long n_global, const DropDev& drop, const TrainBuffers& b, unsigned phases, int* grid_out, void* stream);
 int dispatch_wgrad_x6(const WgradArgs& a, int ns, void* stream);   // pinn_x6_wgrad.hip
@@ -565,7 +569,12 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
       b.dpre_h = a.dpre_h; b.dpre_v1 = a.dpre_v1; b.dpre_v2 = a.dpre_v2;
       b.keep = a.keep; b.du = a.du; b.dz = a.dz; b.loss_part = a.loss_part;
       b.slabs = (float*)(base + w.off_slabs); b.t16 = w.t16; b.n_slices = w.n_slices;
-      if ((rc = launch_train_chain_x6(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, &grid, stream))) return rc;
+      rc = H > 256 ? launch_train_chain_wide(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, &grid, stream)
+                   : launch_train_chain_x6(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, &grid, stream);
+      if (rc) return rc;
+    } else if (H > 256) {
+      const long long t4 = w.t16 / 4;
+      grid = (int)(t4 < 1024 ? (t4 < 1 ? 1 : t4) : 1024);
     } else {
       const long long nt = (n_rows + 127) / 128;
       grid = (int)(nt < cu_count() ? nt : cu_count());

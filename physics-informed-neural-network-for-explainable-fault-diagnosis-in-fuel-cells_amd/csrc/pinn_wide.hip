@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
     for (int ob = 0; ob < nob; ++ob) {
       f32x4 acc[kNT];
       if (EPI == EPI_BACKWARD) {
-        const float s = a.init_w ? a.init_s[valid ? lrow : a.n_rows - 1] : 0.0f;
+        const float s = (a.init_w && valid) ? a.init_s[lrow] : 0.0f;      // padded rows stay exactly zero down the chain
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
           const f32x4 w = a.init_w ? *reinterpret_cast<const f32x4*>(a.init_w + ob * 128 + t * 16 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -273,6 +273,94 @@ __global__ __launch_bounds__(256) void wide_mc_finalize_kernel(const float* accu
   e_u[i] = sqrtf(var);
 }
 
+// heads + aleatoric_loss (01:916-927) + its gradient for the training chain: du, dz per row, loss partial sums per
+// workgroup, and d pre_v2 = wv2 * dz * (1 - v2^2) into the stash
+struct LossArgs {
+  const float* params;
+  const float* h;           // [T16][H][16]  last hidden layer
+  const float* v2;          // [T16][H/4][16]
+  float* dv2;               // [T16][H/4][16]
+  const float* y;
+  float* du; float* dz;     // [T16 * 16]
+  double* loss_part;        // [grid][8]
+  long long n_rows, n_global;
+  int H;
+  long long wp_off, bp_off, wv2_off, bv2_off;
+};
+__global__ __launch_bounds__(256) void wide_loss_kernel(LossArgs a) {
+  __shared__ double red[4][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane >> 4;
+  const long long n_t16 = (a.n_rows + 127) / 128 * 8;
+  const float inv_n = (float)(1.0 / (double)a.n_global);
+  float s_nll = 0.f, s_abs = 0.f, s_mse = 0.f, s_du = 0.f, s_dz = 0.f;
+  for (long long t16 = (long long)blockIdx.x * 4 + wave; t16 < n_t16; t16 += (long long)gridDim.x * 4) {
+    const long long lrow = t16 * 16 + (lane & 15);
+    const bool valid = lrow < a.n_rows;
+    const float* hp = a.h + (t16 * a.H + 4 * kq) * 16 + (lane & 15);
+    const float* vp = a.v2 + (t16 * (a.H / 4) + 4 * kq) * 16 + (lane & 15);
+    float up = 0.f, zp = 0.f;
+    for (int t = 0; t < a.H / 16; ++t) {
+      f32x4 hv;
+      load_block(hp, t, hv);
+      up = block_dot(hv, a.params + a.wp_off + t * 16, kq, up);
+    }
+    for (int t = 0; t < a.H / 64; ++t) {
+      f32x4 vv;
+      load_block(vp, t, vv);
+      zp = block_dot(vv, a.params + a.wv2_off + t * 16, kq, zp);
+    }
+    const float u = sum_kq(up) + a.params[a.bp_off], z = sum_kq(zp) + a.params[a.bv2_off];
+    const float yv = a.y[valid ? lrow : a.n_rows - 1];
+    float du = 0.f, dz = 0.f;
+    {
+      const float sp = softplus_f32(z);
+      const float var = sp + 1e-6f;
+      const float s = logf(var);
+      const float prec = expf(-s);
+      const float e = yv - u;
+      if (valid) {
+        du = -(prec * e) * inv_n;
+        const float sgn = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+        const float ds = (-0.5f * prec * e * e + 0.5f + 0.01f * sgn) * inv_n;
+        const float sig = z > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-z));
+        dz = ds * sig / var;
+        if (kq == 0) {
+          s_nll += 0.5f * prec * e * e + 0.5f * s;
+          s_abs += fabsf(s);
+          s_mse += e * e;
+          s_du += du;
+          s_dz += dz;
+        }
+      }
+      if (lane < 16) { a.du[t16 * 16 + lane] = du; a.dz[t16 * 16 + lane] = dz; }
+    }
+    float* dp = a.dv2 + (t16 * (a.H / 4) + 4 * kq) * 16 + (lane & 15);
+    for (int t = 0; t < a.H / 64; ++t) {
+      f32x4 vv;
+      load_block(vp, t, vv);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(a.params + a.wv2_off + t * 16 + 4 * kq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vv[r] = w[r] * dz * (1.0f - vv[r] * vv[r]);
+      store_block(dp, t, vv);
+    }
+  }
+  float terms[5] = {s_nll, s_abs, s_mse, s_du, s_dz};
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    double v = (double)terms[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    double t = 0.0;
+    if (threadIdx.x < 5)
+      for (int w = 0; w < 4; ++w) t += red[w][threadIdx.x];
+    a.loss_part[(long long)blockIdx.x * 8 + threadIdx.x] = t;
+  }
+}
+
 }  // namespace wide
 
 namespace x6 {
@@ -341,6 +429,67 @@ int launch_forward_wide(const pinn_net_t* net, const FwdArgs& fa, bool mc, void*
     }
     if (mc) hipLaunchKernelGGL(wide_mc_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, accum, (long long)kWideChunk, n, n_passes,
                                fa.o1 + r0, fa.o2 + r0);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PINN_OK : (int)e;
+}
+
+// chain phase of pinn_mlp_train_grads for a wide net: every layer's activation and d pre-activation to the stash (the
+// layout the weight-gradient kernels read); *grid_out = number of loss partials
+int launch_train_chain_wide(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y, long long n_rows,
+                            long long n_global, const DropDev& drop, const TrainBuffers& b, int* grid_out, void* stream) {
+  using namespace wide;
+  hipStream_t st = (hipStream_t)stream;
+  const int H = net->hidden, nh = net->n_hidden;
+  if (drop.mode == PINN_DROP_BITS) return PINN_E_ARCH;
+  ParamLayout L{H, nh};
+  PackLayout K{H, nh};
+  x6::launch_pack_x6(net, d_params, st);
+  const char* packed = (const char*)net->d_packed;
+  const unsigned copy_bytes = (unsigned)(K.total() * 2);
+  const int cus = wide_cus();
+  const long long tiles = (n_rows + 127) / 128;
+  const int grid_l = (int)(tiles < cus ? tiles : cus), grid_s = (int)((tiles * 2 < 4 * cus) ? tiles * 2 : 4 * cus);
+  const long long hs = b.t16 * H * 16;            // floats per hidden-layer stash
+  float* sh = (float*)b.stash_h; float* sv1 = (float*)b.stash_v1; float* sv2 = (float*)b.stash_v2;
+  float* dh = (float*)b.dpre_h; float* dv1 = (float*)b.dpre_v1; float* dv2 = (float*)b.dpre_v2;
+  auto log2i = [](int v) { return 31 - __builtin_clz((unsigned)v); };
+
+  InputArgs ia{d_params, d_x, sh, n_rows, drop.row_offset, H, L.w0(), L.b0(), drop, 0u};
+  hipLaunchKernelGGL(wide_input_kernel, dim3(grid_s), dim3(256), 0, st, ia);
+  LayerArgs la{};
+  la.params = d_params; la.packed = packed; la.copy_bytes = copy_bytes; la.n_rows = n_rows; la.row_base = drop.row_offset; la.drop = drop; la.pass = 0;
+  for (int l = 1; l < nh; ++l) {
+    la.in = sh + (l - 1) * hs; la.out = sh + l * hs; la.IN = H; la.OUT = H; la.mat_off = (unsigned)K.w(l); la.kp_log = log2i(H);
+    la.bias_off = L.b(l); la.layer = l;
+    hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_TANH_DROP>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+  }
+  la.in = sh + (nh - 1) * hs; la.out = sv1; la.IN = H; la.OUT = H / 2; la.mat_off = (unsigned)K.wv0(); la.kp_log = log2i(H);
+  la.bias_off = L.bv0(); la.layer = nh;
+  hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_TANH_DROP>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+  la.in = sv1; la.out = sv2; la.IN = H / 2; la.OUT = H / 4; la.mat_off = (unsigned)K.wv1(); la.kp_log = log2i(round_up64(H / 2));
+  la.bias_off = L.bv1(); la.layer = nh + 1;
+  hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_TANH>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+
+  const long long t4 = b.t16 / 4;
+  const int grid_loss = (int)(t4 < 1024 ? (t4 < 1 ? 1 : t4) : 1024);
+  LossArgs lo{d_params, sh + (nh - 1) * hs, sv2, dv2, d_y, b.du, b.dz, b.loss_part, n_rows, n_global, H, L.wp(), L.bp(), L.wv2(), L.bv2()};
+  hipLaunchKernelGGL(wide_loss_kernel, dim3(grid_loss), dim3(256), 0, st, lo);
+  *grid_out = grid_loss;
+
+  // backward: Wv1^T, Wv0^T (+ w_p du), W_l^T for l = nh-1 .. 1
+  la.init_w = nullptr; la.init_s = nullptr;
+  la.in = dv2; la.out = dv1; la.act = sv1; la.IN = H / 4; la.OUT = H / 2; la.mat_off = (unsigned)K.wv1t(); la.kp_log = log2i(round_up64(H / 4));
+  la.layer = nh;
+  hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_BACKWARD>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+  la.in = dv1; la.out = dh + (nh - 1) * hs; la.act = sh + (nh - 1) * hs; la.IN = H / 2; la.OUT = H; la.mat_off = (unsigned)K.wv0t();
+  la.kp_log = log2i(round_up64(H / 2)); la.layer = nh - 1; la.init_w = d_params + L.wp(); la.init_s = b.du;
+  hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_BACKWARD>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+  la.init_w = nullptr; la.init_s = nullptr;
+  for (int l = nh - 1; l >= 1; --l) {
+    la.in = dh + l * hs; la.out = dh + (l - 1) * hs; la.act = sh + (l - 1) * hs; la.IN = H; la.OUT = H; la.mat_off = (unsigned)K.wt(l);
+    la.kp_log = log2i(H); la.layer = l - 1;
+    hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_BACKWARD>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;

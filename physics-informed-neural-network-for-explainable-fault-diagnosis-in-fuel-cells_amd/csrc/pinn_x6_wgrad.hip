@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
   if (wave >= WI * WJ) return;
   const int wi = wave / WJ, wj = wave % WJ;
   const int hh = lane >> 5, i = lane & 31;
-  const int i0 = wi * TI * 32, j0 = wj * TJ * 32;
+  // blockIdx.y / z: which [32 TI WI] x [32 TJ WJ] block of a larger gradient this workgroup computes
+  const int i0 = blockIdx.y * (TI * 32 * WI) + wi * TI * 32, j0 = blockIdx.z * (TJ * 32 * WJ) + wj * TJ * 32;
+  const bool row_sums = wj == 0 && blockIdx.z == 0, col_sums = wi == 0 && blockIdx.y == 0;
 
   f32x16 acc[TI][TJ];
 #pragma unroll
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
 #pragma unroll
           for (int tj = 0; tj < TJ; ++tj)
             acc[ti][tj] = PINN_MFMA32_BF16(__builtin_bit_cast(bf16x8, pa[ti].p[sa]), __builtin_bit_cast(bf16x8, pb[tj].p[tot - sa]), acc[ti][tj]);
-    if (wj == 0) {
+    if (row_sums) {
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
         }
       }
     }
-    if (wi == 0 && a.dvq) {
+    if (col_sums && a.dvq) {
       const float* ps = a.s1 + t * 16 + 8 * hh;
 #pragma unroll
       for (int sg = 0; sg < 2; ++sg) {
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
         a.dW[so + (long long)row * a.IN + col] = acc[ti][tj][r];
       }
     }
-  if (wj == 0) {
+  if (row_sums) {
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) {
       const float b = bsum[ti] + __shfl_xor(bsum[ti], 32, 64);
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
       }
     }
   }
-  if (wi == 0 && a.dvq) {
+  if (col_sums && a.dvq) {
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
       const float v = vq[tj] + __shfl_xor(vq[tj], 32, 64);
@@ -174,8 +176,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
 
 template <int TI, int TJ, int WI, int WJ>
 static void launch(const WgradArgs& a, int ns, hipStream_t st) {
-  if (ns == 3) hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, 3>), dim3(a.n_slices), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, 2>), dim3(a.n_slices), dim3(256), 0, st, a);
+  const dim3 grid(a.n_slices, a.OUT / (TI * 32 * WI), a.IN / (TJ * 32 * WJ));
+  if (ns == 3) hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, 3>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, 2>), grid, dim3(256), 0, st, a);
 }
 
 }  // namespace x6
@@ -191,6 +194,8 @@ int dispatch_wgrad_x6(const WgradArgs& a, int ns, void* stream) {
   else if (to == 2 && ti == 4) launch<1, 2, 2, 2>(a, ns, st);
   else if (to == 4 && ti == 4) launch<2, 2, 2, 2>(a, ns, st);
   else if (to == 1 && ti == 2) launch<1, 1, 1, 2>(a, ns, st);
+  else if (to % 8 == 0 && ti % 8 == 0) launch<4, 4, 2, 2>(a, ns, st);        // wide nets: blocks of 256 x 256
+  else if (to % 4 == 0 && ti % 8 == 0) launch<2, 4, 2, 2>(a, ns, st);        //            blocks of 128 x 256
   else return PINN_E_ARCH;
   return PINN_OK;
 }

@@ -223,3 +223,44 @@ def test_mc_dropout_wide(lib):
     np.testing.assert_allclose(o[0], np.asarray(pm).reshape(-1), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(o[1], np.asarray(au).reshape(-1), rtol=1e-4)
     np.testing.assert_allclose(o[2], np.asarray(eu).reshape(-1), rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("H,nh,N,mode", [(512, 2, 300, 1), (1024, 4, 200, 1), (512, 1, 129, 0)])
+def test_train_grads_wide_vs_oracle_autograd(lib, H, nh, N, mode):
+    """Training step of a wide net (layer-by-layer x6 kernels + blocked weight-gradient kernels) against torch autograd
+    on the oracle: loss and all 14 gradient tensors at the tolerances of the fused kernels."""
+    import hip_helpers as hh
+    from pinn_amd import synth
+    P = O.init_params([8] + [H] * nh + [1], seed=H + nh)
+    ds = synth.make_dataset(N, (), seed=5)
+    x, y = ds[0], ds[1].reshape(-1)
+    pl = [0.2] * (nh + 1)
+    seed, stream, row0 = 987654321987, 42, 12345
+    drop = hh.dropout_struct(mode, pl, seed=seed, stream_id=stream, row_offset=row0)
+    fp, xd, yd = hh.flat_params(P, H, nh).to(hh.dev()), x.to(hh.dev()).contiguous(), y.to(hh.dev()).contiguous()
+    grads, loss = hh.train_grads(lib, H, nh, fp, xd, yd, drop, precision=2)
+    masks = O.philox_masks_for_net(seed, stream, row0, N, H, nh, pl) if mode == 1 else None
+    lo, mse, go, _, _ = O.nll_loss_and_grads(P, x, ds[1], pl, masks)
+    l = loss.cpu().numpy()
+    assert abs((l[0] + 0.01 * l[1]) / N - lo.item()) <= 2e-5 * abs(lo.item())
+    assert abs(l[2] / N - mse.item()) <= 2e-5 * abs(mse.item())
+    _check_grads(grads, go, H, nh, rtol=2e-4)
+
+
+def test_wide_model_surface():
+    """BASELINE config 5's architecture through the reference-shaped Python surface: trains, predicts, MC-samples."""
+    import pinn_amd
+    from pinn_amd import synth
+    ds = synth.make_dataset(500, (), seed=3)
+    torch.manual_seed(0)
+    m = pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, 1024, 1024, 1024, 1024, 1], ds[4], ds[5], p=0.2, logvar=True, seed=1)
+    m.verbose = False
+    w0 = m.dnn.state_dict()["layers.layer_2.weight"].clone()
+    m.train_dnn(3)
+    assert not torch.equal(w0, m.dnn.state_dict()["layers.layer_2.weight"])
+    u, lv = m.predict(ds[0], ds[4])
+    assert u.shape == (500, 1) and np.all(np.isfinite(u)) and np.all(np.isfinite(lv))
+    pm, au, eu = pinn_amd.get_MC_samples(m, ds[0], ds[4], mc_times=4, dropout=0.4)
+    assert np.all(np.isfinite(pm)) and np.all(au > 0) and np.all(eu > 0)
+    with pytest.raises(Exception):
+        m.dnn.set_precision("fp32"); m.predict(ds[0], ds[4])          # wide nets: x6 arithmetic only
