@@ -50,7 +50,7 @@ def test_host_only_entry_points(lib):
     assert lib.pinn_packed_bytes(ctypes.byref(_lib.Net(8, 1024, 4, _lib.PREC_F32X6))) > 3 * 2 * 4 * 1024 * 1024
     assert lib.pinn_packed_bytes(ctypes.byref(_lib.Net(8, 1024, 4, _lib.PREC_BF16))) == 0
     assert lib.pinn_param_count(ctypes.byref(_lib.Net(8, 384, 2))) < 0
-    for bad in (_lib.Net(8, 96, 3), _lib.Net(7, 256, 3), _lib.Net(8, 256, 0), _lib.Net(8, 512, 3), _lib.Net(8, 256, 9)):
+    for bad in (_lib.Net(8, 96, 3), _lib.Net(7, 256, 3), _lib.Net(8, 256, 0), _lib.Net(8, 384, 3), _lib.Net(8, 256, 9)):
         assert lib.pinn_param_count(ctypes.byref(bad)) == -2
         assert lib.pinn_train_workspace_bytes(ctypes.byref(bad), 1000) == 0
     # struct layouts agree with the C side (sizes from the header's field lists)
