@@ -110,6 +110,24 @@ enum { PINN_STAGE_LAMBDA_PM = 0, /* train_lambda(dnn_para=False): loss mean((y-V
 int pinn_lambda_step(int stage, const double* d_sums, long long n_global, float vn_scale,
                      float lr, int step, float* d_lambda, float* d_adam, float* d_loss, void* stream);
 
+/* ---- a whole physics-parameter stage in ONE launch (01:999-1055, 1098-1151, 1191-1274, 1344-1391).
+ * n_iters iterations, epochs first_epoch .. first_epoch + n_iters - 1, of: residual pass (exactly one of the PINN_RES_*
+ * flags) over all n_rows rows -> gradients of the stage's scalars -> Adam(lr = lr0 * gamma^(epoch / lr_step), the
+ * StepLR schedule) -> clamp; the arithmetic of pinn_residuals + pinn_lambda_step, run by a single persistent
+ * workgroup, so an iteration costs no launch.  For one process holding ALL rows (n_global == n_rows) and
+ * n_rows <= PINN_STAGE_RUN_MAX_ROWS; larger or sharded series iterate the two calls above.
+ * d_adam as in pinn_lambda_step (carried across calls); d_loss float[2] of the last iteration; d_log: NULL, or
+ * float[n_logged][PINN_STAGE_LOG_FLOATS] with one row per epoch divisible by log_every (first_epoch must be):
+ * [0] total loss, [1] physics loss, [2] lr of the following epoch, [3..19] the 17 parameters after the step,
+ * [20..51] the PINN_NSUMS sums of that epoch (float); d_sums: NULL or double[PINN_NSUMS] of the last iteration. */
+#define PINN_STAGE_RUN_MAX_ROWS 65536
+#define PINN_STAGE_LOG_FLOATS 64
+int pinn_lambda_stage_run(int stage, unsigned flags, const float* d_x, const float* d_u, const float* d_y, const pinn_affine_t* aff,
+                          long long n_rows, double lr0, double gamma, int lr_step, int first_epoch, int n_iters, float* d_lambda,
+                          float* d_adam, float* d_loss, float* d_log, int log_every, double* d_sums, void* d_work, size_t work_bytes,
+                          void* stream);
+size_t pinn_lambda_stage_workspace_bytes(long long n_rows);   /* d_work: the rows' parameter-independent terms, computed once per call */
+
 /* ---- the network ------------------------------------------------------------------------
  * Architecture [n_in=8, hidden x n_hidden, 1] + variance head hidden -> hidden/2 -> hidden/4 -> 1
  * (01:389-438).  Parameters live in ONE flat float32 device buffer in state_dict order,

@@ -33,6 +33,7 @@ class Affine(ctypes.Structure):
 
 
 PREC_FP32, PREC_BF16, PREC_F32X6, PREC_F32X6_G3 = 0, 1, 2, 3
+STAGE_RUN_MAX_ROWS, STAGE_LOG_FLOATS = 65536, 64
 
 
 class Net(ctypes.Structure):
@@ -57,6 +58,9 @@ _SIGS = {
     "pinn_residuals": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(Affine), c_void_p, c_uint, c_ll, c_void_p, c_ll,
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "pinn_lambda_step": (c_int, [c_int, c_void_p, c_ll, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pinn_lambda_stage_run": (c_int, [c_int, ctypes.c_uint, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Affine), c_ll, ctypes.c_double,
+                                      ctypes.c_double, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pinn_lambda_stage_workspace_bytes": (c_size_t, [c_ll]),
     "pinn_param_count": (c_ll, [ctypes.POINTER(Net)]),
     "pinn_packed_bytes": (c_size_t, [ctypes.POINTER(Net)]),
     "pinn_mlp_forward": (c_int, [ctypes.POINTER(Net), c_void_p, c_void_p, c_ll, ctypes.POINTER(Dropout), c_void_p, c_void_p,

@@ -37,28 +37,31 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-template <bool kCols>
-__global__ __launch_bounds__(kThreads) void residuals_kernel(
-    const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ y, AffineDev aff,
-    const float* __restrict__ lambdas, unsigned flags, long long n_rows, float* __restrict__ cols, long long ld,
-    double* __restrict__ partials) {
-  __shared__ double red[kThreads / 64][PINN_NSUMS];
-  const float l1 = lambdas[PINN_L1], l2 = lambdas[PINN_L2], l3 = lambdas[PINN_L3];
-  const float lT1 = lambdas[PINN_LT1], lT3 = lambdas[PINN_LT3], lT5 = lambdas[PINN_LT5];
-  const float lH1 = lambdas[PINN_LH1], lH2 = lambdas[PINN_LH2], lH3 = lambdas[PINN_LH3];
-  const float lO1 = lambdas[PINN_LO1], lO2 = lambdas[PINN_LO2], lO3 = lambdas[PINN_LO3];
-
+// the twelve live physics parameters and the constant P_H2O of 01:745-753
+struct LamDev {
+  float l1, l2, l3, lT1, lT3, lT5, lH1, lH2, lH3, lO1, lO2, lO3, P_H2O;
+};
+__device__ __forceinline__ LamDev load_lambdas(const float* __restrict__ lambdas) {
+  LamDev L;
+  L.l1 = lambdas[PINN_L1]; L.l2 = lambdas[PINN_L2]; L.l3 = lambdas[PINN_L3];
+  L.lT1 = lambdas[PINN_LT1]; L.lT3 = lambdas[PINN_LT3]; L.lT5 = lambdas[PINN_LT5];
+  L.lH1 = lambdas[PINN_LH1]; L.lH2 = lambdas[PINN_LH2]; L.lH3 = lambdas[PINN_LH3];
+  L.lO1 = lambdas[PINN_LO1]; L.lO2 = lambdas[PINN_LO2]; L.lO3 = lambdas[PINN_LO3];
   // 01:745-753  P_H2O from Tc = 55 (all float32 tensor ops in the reference)
   const float Tc = 55.0f;
   const float xw = ((-2.1794f + 0.02953f * Tc) - 9.1837e-5f * (Tc * Tc)) + 1.4454e-7f * ((Tc * Tc) * Tc);
-  const float P_H2O = powf(10.0f, xw);
+  L.P_H2O = powf(10.0f, xw);
+  return L;
+}
 
-  float acc[PINN_NSUMS];
-#pragma unroll
-  for (int s = 0; s < PINN_NSUMS; ++s) acc[s] = 0.0f;
+// every term one row contributes (shared by the one-pass kernel and the persistent stage kernel)
+template <bool kCols>
+__device__ __forceinline__ void row_terms(long long row, const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ y,
+                                          const AffineDev& aff, const LamDev& L, unsigned flags, float* __restrict__ cols, long long ld,
+                                          float (&acc)[PINN_NSUMS]) {
+  const float l1 = L.l1, l2 = L.l2, l3 = L.l3, lT1 = L.lT1, lT3 = L.lT3, lT5 = L.lT5, lH1 = L.lH1, lH2 = L.lH2, lH3 = L.lH3;
+  const float lO1 = L.lO1, lO2 = L.lO2, lO3 = L.lO3, P_H2O = L.P_H2O;
 
-  const long long stride = (long long)gridDim.x * kThreads;
-  for (long long row = (long long)blockIdx.x * kThreads + threadIdx.x; row < n_rows; row += stride) {
     const float4 xa = reinterpret_cast<const float4*>(x)[row * 2];
     const float4 xb = reinterpret_cast<const float4*>(x)[row * 2 + 1];
     // the float64 divide of the sklearn-exact de-normalisation is the most expensive op of the pass:
@@ -194,6 +197,21 @@ __global__ __launch_bounds__(kThreads) void residuals_kernel(
     }
   }
 
+template <bool kCols>
+__global__ __launch_bounds__(kThreads) void residuals_kernel(
+    const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ y, AffineDev aff,
+    const float* __restrict__ lambdas, unsigned flags, long long n_rows, float* __restrict__ cols, long long ld,
+    double* __restrict__ partials) {
+  __shared__ double red[kThreads / 64][PINN_NSUMS];
+  const LamDev L = load_lambdas(lambdas);
+  float acc[PINN_NSUMS];
+#pragma unroll
+  for (int s = 0; s < PINN_NSUMS; ++s) acc[s] = 0.0f;
+
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long row = (long long)blockIdx.x * kThreads + threadIdx.x; row < n_rows; row += stride)
+    row_terms<kCols>(row, x, u, y, aff, L, flags, cols, ld, acc);
+
   if (partials == nullptr) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -242,10 +260,9 @@ struct StageDef {
   float lo[5], hi[5];
 };
 
-__global__ void lambda_step_kernel(int stage, const double* __restrict__ sums, double inv_n, float vn_scale, float lr,
-                                   int step, float* __restrict__ lambdas, float* __restrict__ adam,
-                                   float* __restrict__ loss_out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// bc1 = 1 - 0.9^step, bc2 = 1 - 0.999^step (torch computes them in double)
+__device__ void lambda_step_body(int stage, const double* sums, double inv_n, float vn_scale, float lr, double bc1, double bc2, float* lambdas,
+                                 float* adam, float* loss_out) {
   StageDef d;
   float g[5];
   bool has_grad[5];
@@ -294,8 +311,6 @@ __global__ void lambda_step_kernel(int stage, const double* __restrict__ sums, d
     total = physics = (float)(sums[PINN_S_FO2] * inv_n);
   }
   // torch.optim.Adam (single tensor path): bias corrections in double, tensor math in float32
-  const double bc1 = 1.0 - pow(0.9, (double)step);
-  const double bc2 = 1.0 - pow(0.999, (double)step);
   const float step_size = (float)((double)lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
   for (int k = 0; k < d.n; ++k) {
@@ -312,6 +327,225 @@ __global__ void lambda_step_kernel(int stage, const double* __restrict__ sums, d
     lambdas[id] = fminf(fmaxf(p, d.lo[k]), d.hi[k]);       // .data = clamp(.data, lo, hi) AFTER step
   }
   if (loss_out) { loss_out[0] = total; loss_out[1] = physics; }
+}
+
+__global__ void lambda_step_kernel(int stage, const double* __restrict__ sums, double inv_n, float vn_scale, float lr,
+                                   int step, float* __restrict__ lambdas, float* __restrict__ adam,
+                                   float* __restrict__ loss_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  lambda_step_body(stage, sums, inv_n, vn_scale, lr, 1.0 - pow(0.9, (double)step), 1.0 - pow(0.999, (double)step), lambdas, adam, loss_out);
+}
+
+// ---------------------------------------------------------------------------------------
+// Persistent stage driver: a physics-parameter stage is thousands of strictly sequential
+// iterations of "residual pass over all rows -> <= 5 scalar gradients -> Adam -> clamp" (01:1008-1055, 1107-1151,
+// 1204-1274, 1354-1391; 46 007 iterations in the reference schedule).  At the reference's data sizes (1e3 - 1e4
+// rows) three launches per iteration are pure launch latency (~21 us / iteration); here ONE workgroup of 1024
+// threads runs all iterations of a stage: rows from L2, sums in LDS (double, fixed order), StepLR / Adam / clamp by
+// thread 0 on the LDS copy of the parameters, a log row every `log_every` epochs.
+// ---------------------------------------------------------------------------------------
+constexpr int kStageThreads = 1024;
+constexpr int kLogFloats = PINN_STAGE_LOG_FLOATS;   // [0..1] total / physics loss, [2] lr of the next epoch, [3..19] lambdas, [20..51] sums
+constexpr int kCacheFloats = 6;
+
+// Everything of a row that does not depend on the stage's parameters is computed ONCE (the de-normalisation with its
+// float64 divides, powf / expf of the Nernst terms, the flow ratios): 6 floats per row, struct-of-arrays in d_work.
+// Same operations in the same order as row_terms, so the two paths differ only in the order of the row sums.
+__device__ __forceinline__ void stage_prepare(long long row, const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ y,
+                                              const AffineDev& aff, float P_H2O, unsigned flags, float (&c)[kCacheFloats]) {
+  const float4 xa = reinterpret_cast<const float4*>(x)[row * 2];
+  const float4 xb = reinterpret_cast<const float4*>(x)[row * 2 + 1];
+  const float r0 = denorm(xa.x, aff.x_min[0], aff.x_scale[0]);
+  const float i5 = r0 / 270.0f + 1e-5f;
+  const float It = i5 * 270.0f;
+#pragma unroll
+  for (int k = 0; k < kCacheFloats; ++k) c[k] = 0.0f;
+  if (flags & PINN_RES_V) {
+    const float r3 = denorm(xa.w, aff.x_min[3], aff.x_scale[3]), r4 = denorm(xb.x, aff.x_min[4], aff.x_scale[4]);
+    const float r5 = denorm(xb.y, aff.x_min[5], aff.x_scale[5]);
+    const float un = u[row];
+    const float Tk = r5 + 273.15f;
+    const float P_H2 = r3 / 101.0f + 1.0f;
+    const float P_air = r4 / 101.0f + 1.0f;
+    const float Tk_p = powf(Tk, 1.334f);
+    const float pp_H2 = 0.5f * (P_H2 / expf(1.653f * i5 / Tk_p) - P_H2O);
+    const float pp_O2 = P_air / expf(4.192f * i5 / Tk_p) - P_H2O;
+    const float RT = 8.314f * Tk;
+    c[0] = i5;
+    c[1] = RT / 96485.0f;
+    c[2] = 220170.0f / 192970.0f - (RT * logf(P_H2O / (pp_H2 * sqrtf(pp_O2)))) / 192970.0f;
+    c[3] = denorm(un, aff.y_min, aff.y_scale) / 5.0f;
+    c[4] = y[row];
+    c[5] = un;
+  } else if (flags & PINN_RES_T) {
+    const float r1 = denorm(xa.y, aff.x_min[1], aff.x_scale[1]), r2 = denorm(xa.z, aff.x_min[2], aff.x_scale[2]);
+    const float r5 = denorm(xb.y, aff.x_min[5], aff.x_scale[5]);
+    const float i6 = r0 / 270.0f + 1e-6f;
+    c[0] = i6 * 270.0f; c[1] = r1 + 1e-6f; c[2] = r2; c[3] = r5;
+  } else if (flags & PINN_RES_H) {
+    const float r6 = denorm(xb.z, aff.x_min[6], aff.x_scale[6]);
+    float Q = ((It / 192970.0f) * 5.0f) * 22.4f;
+    Q = Q * 60.0f;
+    Q = fmaxf(Q, 1e-8f);
+    c[0] = It; c[1] = (r6 + 1e-6f) / Q;
+  } else {
+    const float r7 = denorm(xb.w, aff.x_min[7], aff.x_scale[7]);
+    float Q = ((It * 5.0f) / 385940.0f) * 22.4f;
+    Q = Q * 60.0f;
+    Q = fmaxf(Q, 1e-8f);
+    c[0] = It; c[1] = ((r7 + 1e-6f) * 0.21f) / Q;
+  }
+}
+// the parameter-dependent rest (row_terms' formulas)
+__device__ __forceinline__ void stage_terms(const float (&c)[kCacheFloats], const AffineDev& aff, const LamDev& L, unsigned flags,
+                                            float (&acc)[PINN_NSUMS]) {
+  if (flags & PINN_RES_V) {
+    const float i5 = c[0], b = c[1], E = c[2], V_out = c[3], yv = c[4], un = c[5];
+    const float V_act = (-b) * logf(i5 / L.l2);
+    const float V_ohm = -(i5 * L.l1);
+    const float V_conc = (0.5f * b) * logf(1.0f - i5 / L.l3);
+    const float V_est = ((E + V_act) + V_ohm) + V_conc;
+    const float f = V_est - V_out;
+    const float V_est5 = V_est * 5.0f;
+    const float d1 = -i5;
+    const float d2 = b / L.l2;
+    const float d3 = 0.5f * b * i5 / (L.l3 * (L.l3 - i5));
+    acc[PINN_S_FV2] += f * f;
+    acc[PINN_S_FV_D1] += f * d1;
+    acc[PINN_S_FV_D2] += f * d2;
+    acc[PINN_S_FV_D3] += f * d3;
+    const float Vn = V_est5 * aff.vn_scale + aff.vn_min;
+    const float dy = yv - Vn;
+    acc[PINN_S_YV2] += dy * dy;
+    acc[PINN_S_YV_D1] += dy * d1;
+    acc[PINN_S_YV_D2] += dy * d2;
+    acc[PINN_S_YV_D3] += dy * d3;
+    const float du = yv - un;
+    acc[PINN_S_YU2] += du * du;
+  } else if (flags & PINN_RES_T) {
+    const float It6 = c[0], mc = c[1], r2 = c[2], r5 = c[3];
+    const float T_pred = ((L.lT1 * It6 + L.lT3 * mc) + 0.5f * r2) + L.lT5;
+    const float f = r5 - T_pred;
+    acc[PINN_S_FT2] += f * f;
+    acc[PINN_S_FT_D1] += f * (-It6);
+    acc[PINN_S_FT_D3] += f * (-mc);
+    acc[PINN_S_FT_D5] += -f;
+    acc[PINN_S_FT_ABS] += fabsf(f);
+  } else if (flags & PINN_RES_H) {
+    const float It = c[0], act = c[1];
+    const bool lin = It <= L.lH3;
+    const float tgt = lin ? (L.lH1 + L.lH2 * (It / 100.0f)) : (L.lH1 + L.lH2 * (L.lH3 / 100.0f));
+    const float f = act - tgt;
+    acc[PINN_S_FH2] += f * f;
+    acc[PINN_S_FH_D1] += -f;
+    acc[PINN_S_FH_D2] += f * (-(lin ? It / 100.0f : L.lH3 / 100.0f));
+    acc[PINN_S_FH_D3] += f * (-(lin ? 0.0f : L.lH2 / 100.0f));
+    acc[PINN_S_ACTH] += act;
+    acc[PINN_S_TGTH] += tgt;
+  } else {
+    const float It = c[0], act = c[1];
+    const float thr = fabsf(L.lO3);
+    const bool lin = It <= thr;
+    const float raw = lin ? (L.lO1 + L.lO2 * (It / 100.0f)) : (L.lO1 + L.lO2 * (thr / 100.0f));
+    const float tgt = fminf(fmaxf(raw, 1.05f), 15.0f);
+    const float cl = (raw >= 1.05f && raw <= 15.0f) ? 1.0f : 0.0f;
+    const float f = (act - tgt) + fmaxf(1.0f - act, 0.0f) * 10.0f;
+    const float sgn = (L.lO3 > 0.0f) ? 1.0f : ((L.lO3 < 0.0f) ? -1.0f : 0.0f);
+    acc[PINN_S_FO2] += f * f;
+    acc[PINN_S_FO_D1] += f * (-cl);
+    acc[PINN_S_FO_D2] += f * (-cl * (lin ? It / 100.0f : thr / 100.0f));
+    acc[PINN_S_FO_D3] += f * (-cl * (lin ? 0.0f : L.lO2 * sgn / 100.0f));
+    acc[PINN_S_ACTO] += act;
+    acc[PINN_S_TGTO] += tgt;
+  }
+}
+
+__global__ __launch_bounds__(kStageThreads) void stage_run_kernel(
+    int stage, unsigned flags, const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ y, AffineDev aff,
+    long long n_rows, double lr0, double gamma, int lr_step, int first_epoch, int n_iters, float* __restrict__ lambdas,
+    float* __restrict__ adam, float* __restrict__ loss_out, float* __restrict__ log, int log_every, double* __restrict__ sums_out,
+    float* __restrict__ work) {
+  __shared__ double red[kStageThreads / 64][PINN_NSUMS];
+  __shared__ double sums[PINN_NSUMS];
+  __shared__ float lam_s[PINN_NLAMBDA], adam_s[2 * PINN_NLAMBDA], loss_s[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < PINN_NLAMBDA) lam_s[tid] = lambdas[tid];
+  if (tid < 2 * PINN_NLAMBDA) adam_s[tid] = adam[tid];
+  // the sums this stage reads: a contiguous range of the enum
+  int s_lo, s_hi;
+  if (flags & PINN_RES_V) { s_lo = PINN_S_FV2; s_hi = PINN_S_YU2 + 1; }
+  else if (flags & PINN_RES_T) { s_lo = PINN_S_FT2; s_hi = PINN_S_FT_ABS + 1; }
+  else if (flags & PINN_RES_H) { s_lo = PINN_S_FH2; s_hi = PINN_S_TGTH + 1; }
+  else { s_lo = PINN_S_FO2; s_hi = PINN_S_TGTO + 1; }
+  if (tid < PINN_NSUMS) sums[tid] = 0.0;
+  {   // parameter-independent part of every row, once
+    const LamDev L0 = load_lambdas(lambdas);
+    for (long long row = tid; row < n_rows; row += kStageThreads) {
+      float c[kCacheFloats];
+      stage_prepare(row, x, u, y, aff, L0.P_H2O, flags, c);
+#pragma unroll
+      for (int k = 0; k < kCacheFloats; ++k) work[k * n_rows + row] = c[k];
+    }
+  }
+  __syncthreads();
+  const int n_cached = (flags & PINN_RES_V) ? 6 : ((flags & PINN_RES_T) ? 4 : 2);
+  const double inv_n = 1.0 / (double)n_rows;
+  // thread 0's optimizer state: beta^step as running products (pow() once), the StepLR rate recomputed at its edges
+  double b1p = pow(0.9, (double)first_epoch), b2p = pow(0.999, (double)first_epoch);
+  float lr = (float)(lr0 * pow(gamma, (double)(first_epoch / lr_step)));
+  for (int it = 0; it < n_iters; ++it) {
+    const int epoch = first_epoch + it;
+    const LamDev L = load_lambdas(lam_s);
+    float acc[PINN_NSUMS];
+#pragma unroll
+    for (int s = 0; s < PINN_NSUMS; ++s) acc[s] = 0.0f;
+    // four rows per trip: their (L2) loads are all in flight before the first is used
+    for (long long row0 = tid; row0 < n_rows; row0 += 4 * kStageThreads) {
+      float c[4][kCacheFloats];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long long row = row0 + q * kStageThreads;
+        const long long rr = row < n_rows ? row : row0;
+#pragma unroll
+        for (int k = 0; k < kCacheFloats; ++k) c[q][k] = k < n_cached ? work[k * n_rows + rr] : 0.0f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (row0 + q * kStageThreads < n_rows) stage_terms(c[q], aff, L, flags, acc);
+    }
+#pragma unroll
+    for (int s = 0; s < PINN_NSUMS; ++s) {
+      if (s >= s_lo && s < s_hi) {                   // block-uniform
+        const double w = wave_sum((double)acc[s]);
+        if (lane == 0) red[wave][s] = w;
+      }
+    }
+    __syncthreads();
+    if (tid >= s_lo && tid < s_hi) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < kStageThreads / 64; ++w) t += red[w][tid];
+      sums[tid] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      if (it > 0 && epoch % lr_step == 0) lr = (float)(lr0 * pow(gamma, (double)(epoch / lr_step)));
+      b1p *= 0.9; b2p *= 0.999;
+      lambda_step_body(stage, sums, inv_n, aff.vn_scale, lr, 1.0 - b1p, 1.0 - b2p, lam_s, adam_s, loss_s);
+      if (log && log_every > 0 && epoch % log_every == 0) {
+        float* row = log + (long long)(epoch / log_every - first_epoch / log_every) * kLogFloats;
+        row[0] = loss_s[0]; row[1] = loss_s[1];
+        row[2] = (float)(lr0 * pow(gamma, (double)((epoch + 1) / lr_step)));
+        for (int k = 0; k < PINN_NLAMBDA; ++k) row[3 + k] = lam_s[k];
+        for (int k = 0; k < PINN_NSUMS; ++k) row[20 + k] = (float)sums[k];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < PINN_NLAMBDA) lambdas[tid] = lam_s[tid];
+  if (tid < 2 * PINN_NLAMBDA) adam[tid] = adam_s[tid];
+  if (tid < 2 && loss_out) loss_out[tid] = loss_s[tid];
+  if (tid < PINN_NSUMS && sums_out) sums_out[tid] = sums[tid];
 }
 
 }  // namespace
@@ -353,6 +587,30 @@ extern "C" int pinn_lambda_step(int stage, const double* d_sums, long long n_glo
   (void)hipGetLastError();
   hipLaunchKernelGGL(lambda_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stage, d_sums, 1.0 / (double)n_global,
                      vn_scale, lr, step, d_lambda, d_adam, d_loss);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PINN_OK : (int)e;
+}
+
+extern "C" size_t pinn_lambda_stage_workspace_bytes(long long n_rows) { return n_rows > 0 ? (size_t)n_rows * 6 * sizeof(float) : 0; }
+
+extern "C" int pinn_lambda_stage_run(int stage, unsigned flags, const float* d_x, const float* d_u, const float* d_y, const pinn_affine_t* aff,
+                                     long long n_rows, double lr0, double gamma, int lr_step, int first_epoch, int n_iters, float* d_lambda,
+                                     float* d_adam, float* d_loss, float* d_log, int log_every, double* d_sums, void* d_work, size_t work_bytes,
+                                     void* stream) {
+  if (stage < 0 || stage > PINN_STAGE_OXYGEN || !d_x || !aff || !d_lambda || !d_adam || n_rows <= 0 || n_rows > PINN_STAGE_RUN_MAX_ROWS ||
+      n_iters < 0 || first_epoch < 0 || lr_step < 1)
+    return PINN_E_ARG;
+  if (flags != PINN_RES_V && flags != PINN_RES_T && flags != PINN_RES_H && flags != PINN_RES_O) return PINN_E_ARG;
+  if ((flags & PINN_RES_V) && (!d_u || !d_y)) return PINN_E_ARG;
+  if (d_log && log_every > 0 && first_epoch % log_every) return PINN_E_ARG;
+  if (!d_work || work_bytes < pinn_lambda_stage_workspace_bytes(n_rows)) return PINN_E_WORKSPACE;
+  if (n_iters == 0) return PINN_OK;
+  (void)hipGetLastError();
+  AffineDev a;
+  for (int c = 0; c < 8; ++c) { a.x_min[c] = aff->x_min[c]; a.x_scale[c] = aff->x_scale[c]; }
+  a.y_min = aff->y_min; a.y_scale = aff->y_scale; a.vn_scale = aff->vn_scale; a.vn_min = aff->vn_min;
+  hipLaunchKernelGGL(stage_run_kernel, dim3(1), dim3(kStageThreads), 0, (hipStream_t)stream, stage, flags, d_x, d_u, d_y, a, n_rows, lr0, gamma,
+                     lr_step, first_epoch, n_iters, d_lambda, d_adam, d_loss, d_log, log_every, d_sums, (float*)d_work);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;
 }

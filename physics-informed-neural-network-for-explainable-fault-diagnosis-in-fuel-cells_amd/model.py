@@ -422,6 +422,23 @@ class PhysicsInformedNN():
         adam = torch.zeros(2 * _lib.NLAMBDA, dtype=torch.float32, device=dev)
         loss = torch.zeros(2, dtype=torch.float32, device=dev)
         lam = self._lambdas()
+        if self._group is None and self.n_global == self.n_local and 0 < self.n_local <= self.stage_run_max_rows and nIter > 0:
+            # the reference's data sizes: the whole stage in ONE launch (persistent workgroup)
+            n_log = (nIter + 999) // 1000
+            log = torch.zeros(n_log, _lib.STAGE_LOG_FLOATS, dtype=torch.float32, device=dev)
+            wb = self._lib.pinn_lambda_stage_workspace_bytes(self.n_local)
+            work = torch.empty(wb, dtype=torch.uint8, device=dev)
+            rc = self._lib.pinn_lambda_stage_run(stage, flags, _ptr(x), _ptr(u), _ptr(y), ctypes.byref(aff), self.n_local, lr0, gamma, 1000, 0,
+                                                 nIter, _ptr(lam), _ptr(adam), _ptr(loss), _ptr(log), 1000, _ptr(self._sums), _ptr(work), wb,
+                                                 _stream())
+            _lib.check(rc, "pinn_lambda_stage_run")
+            rows = log.cpu().numpy()
+            for k in range(n_log):
+                self._lambda_log_view = rows[k, 3:20]
+                log_fn(1000 * k, rows[k, 0:2], rows[k, 20:20 + 32].astype("float64"), float(rows[k, 2]))
+            self._lambda_log_view = None
+            self.last_loss = float(loss[0].item())
+            return
         for epoch in range(nIter):
             lr = lr0 * gamma ** (epoch // 1000)
             rc = self._lib.pinn_residuals(_ptr(x), _ptr(u), _ptr(y), ctypes.byref(aff), _ptr(lam), flags, self.n_local,
@@ -434,6 +451,9 @@ class PhysicsInformedNN():
             if epoch % 1000 == 0:
                 log_fn(epoch, loss.cpu().numpy(), self._sums.cpu().numpy(), lr0 * gamma ** ((epoch + 1) // 1000))
         self.last_loss = float(loss[0].item()) if nIter > 0 else None
+
+    stage_run_max_rows = 32768      # <= _lib.STAGE_RUN_MAX_ROWS; larger series iterate the multi-workgroup kernels
+    _lambda_log_view = None
 
     def _freeze_all_but(self, live):
         for n in LAMBDA_NAMES:
@@ -448,7 +468,7 @@ class PhysicsInformedNN():
         self._log('  Epoch | total loss | phys loss |   l1    |    l2     |   l3   |    LR    ')
 
         def log(epoch, loss, sums, lr):
-            l = self._lambda.cpu().numpy()
+            l = self._lambda_log_view if self._lambda_log_view is not None else self._lambda.cpu().numpy()
             self._log(f' {epoch:5d}  | {loss[0]:9.3e} | {loss[1]:10.3e} | {l[0]:7.4f} | {l[1]:9.2e} | {l[2]:6.3f} | {lr:8.1e}')
         self._run_lambda_stage(_lib.STAGE_LAMBDA_F if dnn_para else _lib.STAGE_LAMBDA_PM, nIter, _lib.RES_V, 1e-3, 0.8, True, log)
 
@@ -461,7 +481,7 @@ class PhysicsInformedNN():
         self._log(' Epoch |   Loss    |  MAE(C)  |   T1    |   T2   |   T3   |   T4   |    T5    |    LR   |')
 
         def log(epoch, loss, sums, lr):
-            l = self._lambda.cpu().numpy()
+            l = self._lambda_log_view if self._lambda_log_view is not None else self._lambda.cpu().numpy()
             mae = sums[_lib.S["FT_ABS"]] / self.n_global
             self._log(f' {epoch:3d}   | {loss[0]:9.3e} | {mae:8.2f} | {l[4]:7.4f} | {l[5]:6.3f} | {l[6]:6.3f} | {l[7]:6.2f} | {l[8]:6.2f} |{lr:8.1e}')
         self._run_lambda_stage(_lib.STAGE_THERMAL, nIter, _lib.RES_T, 1.0, 0.8, False, log)
@@ -475,7 +495,7 @@ class PhysicsInformedNN():
         self._log(' Epoch |   Loss    |   actual   |   target   |   H1    |   H2   |   H3   |   H4   |    LR    ')
 
         def log(epoch, loss, sums, lr):
-            l = self._lambda.cpu().numpy()
+            l = self._lambda_log_view if self._lambda_log_view is not None else self._lambda.cpu().numpy()
             self._log(f' {epoch:3d}   | {loss[0]:9.3e} | {sums[_lib.S["ACTH"]] / self.n_global:10.3f} | '
                       f'{sums[_lib.S["TGTH"]] / self.n_global:10.3f} | {l[9]:7.4f} | {l[10]:6.3f} | {l[11]:6.3f} | {l[12]:6.2f} | {lr:8.1e}')
         self._run_lambda_stage(_lib.STAGE_HYDROGEN, nIter, _lib.RES_H, 1e-1, 0.9, False, log)
@@ -489,7 +509,7 @@ class PhysicsInformedNN():
         self._log(' Epoch |   Loss    |   actual   |   target   |   O1    |   O2   |   O3   |   O4   |    LR    ')
 
         def log(epoch, loss, sums, lr):
-            l = self._lambda.cpu().numpy()
+            l = self._lambda_log_view if self._lambda_log_view is not None else self._lambda.cpu().numpy()
             self._log(f' {epoch:3d}   | {loss[0]:6.3e} | {sums[_lib.S["ACTO"]] / self.n_global:6.3f} | '
                       f'{sums[_lib.S["TGTO"]] / self.n_global:6.3f} | {l[13]:7.2f} | {l[14]:6.3f} | {abs(l[15]):6.1f}A | {l[16]:5.2f} | {lr:8.1e}')
         self._run_lambda_stage(_lib.STAGE_OXYGEN, nIter, _lib.RES_O, 1e-2, 0.9, False, log)

@@ -158,3 +158,25 @@ def test_config1_end_to_end_small():
     arr = pinn_amd.create_comprehensive_results_array_v2(m, ds, mc_times=8, dropout=0.4)
     assert arr.shape == (2200, 22) and np.all(np.isfinite(arr))
     assert set(np.unique(arr[:, 17])) == {0.0, 1.0}
+
+
+def test_stage_run_persistent_matches_iterated_kernels():
+    """the whole-stage persistent kernel (pinn_lambda_stage_run) against the same stage iterated through
+    pinn_residuals + pinn_lambda_step (only the order of the row sums differs), all five stage trainers, 300 iterations
+    across... (StepLR boundaries are covered by the golden trajectory test, which runs through the persistent path)."""
+    import pinn_amd
+    from pinn_amd import synth
+    ds = synth.make_dataset(5000, (), seed=4)
+
+    def run(persistent):
+        torch.manual_seed(0)
+        m = pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, 128, 128, 1], ds[4], ds[5], p=0.2, logvar=True, seed=2)
+        m.verbose = False
+        if not persistent:
+            m.stage_run_max_rows = 0
+        m.train_lambda(300, False); m.train_lambda(300, True); m.train_thermal(300); m.train_hydrogen(300); m.train_oxygen(300)
+        return m._lambda.cpu().numpy().copy(), m.last_loss
+    a, la = run(True)
+    b, lb = run(False)
+    np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-9)
+    assert abs(la - lb) <= 1e-5 * abs(lb)
