@@ -5,7 +5,7 @@ from pinn_amd import _lib
 import hip_helpers as hh
 import pinn_oracle as O
 lib = _lib.load()
-H, nh, N = 256, 3, 1_000_000
+H, nh, N = int(os.environ.get("PINN_H", "256")), 3, 1_000_000
 P = O.init_params([8, H, H, H, 1], seed=1)
 fp = hh.flat_params(P, H, nh).to(hh.dev())
 x = torch.rand(N, 8, device=hh.dev())
