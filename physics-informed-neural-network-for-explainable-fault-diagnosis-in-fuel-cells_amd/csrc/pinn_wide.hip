@@ -18,7 +18,6 @@ namespace wide {
 using namespace x6;
 
 constexpr int kWideChunk = 65536;        // rows per pass through the layer kernels (a multiple of 128)
-constexpr int kNT = 8;                   // 128 output features per accumulator set
 
 enum { EPI_TANH_DROP = 0, EPI_TANH = 1, EPI_BACKWARD = 2 };
 
@@ -54,8 +53,11 @@ __device__ __forceinline__ void piece_rt(Pipe6& pipe, unsigned off, int kp_log, 
   __builtin_amdgcn_global_load_lds((gptr_t)(pipe.packed + goff + voff), (lptr_t)dst, 16, 0, 0);
 }
 
-template <int EPI>
+// kNT accumulator blocks = 16 kNT output features per pass over the K-groups: 16 (256 features, half the input
+// re-reads and fragment splits) when OUT allows, else 8
+template <int EPI, int kNT>
 __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a) {
+  constexpr int kOB = 16 * kNT, kNrb = kNT == 16 ? 4 : 3, kPieces = (3 << kNrb) / 8;     // features per pass; log2(16-row blocks); pieces per wave
   constexpr int kRingBytes = 8 * 2 * 2048;
   constexpr int kSlabAt = (kRingBytes + 1023) & ~1023;
   __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * kSlabBytes];
@@ -64,11 +66,11 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
   pipe.init(threadIdx.x);
   const int lane = threadIdx.x & 63, wave = pipe.wave, kq = lane >> 4;
   const StashRing ring{smem + wave * 4096, lane};
-  const int NG = a.IN / 32, nob = a.OUT / 128;
-  auto slab_off = [&](int ob, int g) { return a.mat_off + ((unsigned)(ob * 128) << a.kp_log) + 32u * (unsigned)g; };
+  const int NG = a.IN / 32, nob = a.OUT / kOB;
+  auto slab_off = [&](int ob, int g) { return a.mat_off + ((unsigned)(ob * kOB) << a.kp_log) + 32u * (unsigned)g; };
   // slab (0, 0)
   pipe.par = 0;
-  for (int j = 0; j < 3; ++j) piece_rt(pipe, slab_off(0, 0), a.kp_log, 3, j, 0);
+  for (int j = 0; j < kPieces; ++j) piece_rt(pipe, slab_off(0, 0), a.kp_log, kNrb, j, 0);
   __syncthreads();
 
   const long long n_tiles = (a.n_rows + kTileRowsX - 1) / kTileRowsX;
@@ -96,11 +98,11 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
         const float s = (a.init_w && valid) ? a.init_s[lrow] : 0.0f;      // padded rows stay exactly zero down the chain
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
-          const f32x4 w = a.init_w ? *reinterpret_cast<const f32x4*>(a.init_w + ob * 128 + t * 16 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+          const f32x4 w = a.init_w ? *reinterpret_cast<const f32x4*>(a.init_w + ob * kOB + t * 16 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
           acc[t] = w * s;
         }
       } else {
-        bias_blocks<kNT>(acc, a.params + a.bias_off + ob * 128, kq);
+        bias_blocks<kNT>(acc, a.params + a.bias_off + ob * kOB, kq);
       }
 #pragma unroll 1
       for (int g = 0; g < NG; ++g) {
@@ -109,15 +111,17 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
         const int ob2 = last_g ? (ob + 1 < nob ? ob + 1 : 0) : ob, g2 = last_g ? 0 : g + 1;
         const unsigned off2 = slab_off(ob2, g2);
         const int gb = g2, gf = g + 2 < NG ? g + 2 : g + 2 - NG;
+        // slots = tile pairs (kNT / 2): the weight pieces first, the ring fetch in the last one
         auto dma = [&](auto slotc) {
           constexpr int slot = decltype(slotc)::value;
-          if constexpr (slot < 3) piece_rt(pipe, off2, a.kp_log, 3, slot, pipe.par ^ 1);
-          if constexpr (slot == 3) fetch(gf);
+          if constexpr (slot < kPieces) piece_rt(pipe, off2, a.kp_log, kNrb, slot, pipe.par ^ 1);
+          if constexpr (slot == kNT / 2 - 1) fetch(gf);
         };
+        // chunks = tiles: the four register pairs of the next block, evenly spread
         auto vchunk = [&](auto cc) {
-          constexpr int ci = decltype(cc)::value;
-          if constexpr (ci % 2 == 1) {
-            constexpr int r = ci / 2;
+          constexpr int ci = decltype(cc)::value, every = kNT / 4;
+          if constexpr (ci % every == every - 1) {
+            constexpr int r = ci / every;
             split_pair<r>(ring.read(gb & 1, 0, r), ring.read(gb & 1, 1, r), st.out);
           }
         };
@@ -126,10 +130,10 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
         cur = st.out;
       }
       // ---- epilogue of these 128 output features
-      float* out_tile = a.out + (t16 * a.OUT + ob * 128 + 4 * kq) * 16 + (lane & 15);
+      float* out_tile = a.out + (t16 * a.OUT + ob * kOB + 4 * kq) * 16 + (lane & 15);
       if (EPI == EPI_BACKWARD) {
         const float scale = a.drop.mode != PINN_DROP_NONE ? a.drop.scale[a.layer] : 1.0f, inv_scale = 1.0f / scale;
-        const float* hp = a.act + (t16 * a.OUT + ob * 128 + 4 * kq) * 16 + (lane & 15);
+        const float* hp = a.act + (t16 * a.OUT + ob * kOB + 4 * kq) * 16 + (lane & 15);
         f32x4 hl[kNT];
 #pragma unroll
         for (int t = 0; t < kNT; ++t) load_block(hp, t, hl[t]);
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
         const LayerDrop ldr = layer_drop(a.drop, c.mode, a.layer);
 #pragma unroll
         for (int k = 0; k < kNT / 2; ++k) {
-          const unsigned keep = activate_pair<false>(acc[2 * k], acc[2 * k + 1], a.drop, c, ldr, a.layer, ob * 4 + k);
+          const unsigned keep = activate_pair<false>(acc[2 * k], acc[2 * k + 1], a.drop, c, ldr, a.layer, ob * (kNT / 2) + k);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             acc[2 * k][r] = stash_value(acc[2 * k][r], (keep >> r) & 1u);
@@ -368,6 +372,12 @@ void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st
 }
 
 // scratch behind the packed weights (floats): two activation buffers, v1, v2, the MC sums
+template <int EPI>
+static void launch_wide_layer(const wide::LayerArgs& la, int grid, hipStream_t st) {
+  if (la.OUT % 256 == 0) hipLaunchKernelGGL((wide::wide_layer_x6_kernel<EPI, 16>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
+  else hipLaunchKernelGGL((wide::wide_layer_x6_kernel<EPI, 8>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
+}
+
 size_t wide_scratch_floats(int H) {
   return (size_t)wide::kWideChunk * (2 * (size_t)H + H / 2 + H / 4 + 4);
 }
@@ -413,15 +423,15 @@ int launch_forward_wide(const pinn_net_t* net, const FwdArgs& fa, bool mc, void*
       for (int l = 1; l < nh; ++l) {
         la.in = cur; la.out = nxt; la.IN = H; la.OUT = H; la.mat_off = (unsigned)K.w(l); la.kp_log = 31 - __builtin_clz((unsigned)H);
         la.bias_off = L.b(l); la.layer = l;
-        hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_TANH_DROP>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+        launch_wide_layer<EPI_TANH_DROP>(la, grid_l, st);
         float* t = cur; cur = nxt; nxt = t;
       }
       la.in = cur; la.out = v1; la.IN = H; la.OUT = H / 2; la.mat_off = (unsigned)K.wv0(); la.kp_log = 31 - __builtin_clz((unsigned)H);
       la.bias_off = L.bv0(); la.layer = nh;
-      hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_TANH_DROP>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+      launch_wide_layer<EPI_TANH_DROP>(la, grid_l, st);
       la.in = v1; la.out = v2; la.IN = H / 2; la.OUT = H / 4; la.mat_off = (unsigned)K.wv1(); la.kp_log = 31 - __builtin_clz((unsigned)round_up64(H / 2));
       la.bias_off = L.bv1(); la.layer = nh + 1;
-      hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_TANH>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+      launch_wide_layer<EPI_TANH>(la, grid_l, st);
       HeadArgs ha{fa.params, cur, v2, n, H, L.wp(), L.bp(), L.wv2(), L.bv2(), mc ? (pass < 0 ? 1 : 2) : 0,
                   fa.o0 + r0, mc ? nullptr : fa.o1 + r0, accum, kWideChunk};
       hipLaunchKernelGGL(wide_heads_kernel, dim3(grid_s), dim3(256), 0, st, ha);
@@ -462,14 +472,14 @@ int launch_train_chain_wide(const pinn_net_t* net, const float* d_params, const 
   for (int l = 1; l < nh; ++l) {
     la.in = sh + (l - 1) * hs; la.out = sh + l * hs; la.IN = H; la.OUT = H; la.mat_off = (unsigned)K.w(l); la.kp_log = log2i(H);
     la.bias_off = L.b(l); la.layer = l;
-    hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_TANH_DROP>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+    launch_wide_layer<EPI_TANH_DROP>(la, grid_l, st);
   }
   la.in = sh + (nh - 1) * hs; la.out = sv1; la.IN = H; la.OUT = H / 2; la.mat_off = (unsigned)K.wv0(); la.kp_log = log2i(H);
   la.bias_off = L.bv0(); la.layer = nh;
-  hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_TANH_DROP>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+  launch_wide_layer<EPI_TANH_DROP>(la, grid_l, st);
   la.in = sv1; la.out = sv2; la.IN = H / 2; la.OUT = H / 4; la.mat_off = (unsigned)K.wv1(); la.kp_log = log2i(round_up64(H / 2));
   la.bias_off = L.bv1(); la.layer = nh + 1;
-  hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_TANH>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+  launch_wide_layer<EPI_TANH>(la, grid_l, st);
 
   const long long t4 = b.t16 / 4;
   const int grid_loss = (int)(t4 < 1024 ? (t4 < 1 ? 1 : t4) : 1024);
@@ -481,15 +491,15 @@ int launch_train_chain_wide(const pinn_net_t* net, const float* d_params, const 
   la.init_w = nullptr; la.init_s = nullptr;
   la.in = dv2; la.out = dv1; la.act = sv1; la.IN = H / 4; la.OUT = H / 2; la.mat_off = (unsigned)K.wv1t(); la.kp_log = log2i(round_up64(H / 4));
   la.layer = nh;
-  hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_BACKWARD>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+  launch_wide_layer<EPI_BACKWARD>(la, grid_l, st);
   la.in = dv1; la.out = dh + (nh - 1) * hs; la.act = sh + (nh - 1) * hs; la.IN = H / 2; la.OUT = H; la.mat_off = (unsigned)K.wv0t();
   la.kp_log = log2i(round_up64(H / 2)); la.layer = nh - 1; la.init_w = d_params + L.wp(); la.init_s = b.du;
-  hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_BACKWARD>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+  launch_wide_layer<EPI_BACKWARD>(la, grid_l, st);
   la.init_w = nullptr; la.init_s = nullptr;
   for (int l = nh - 1; l >= 1; --l) {
     la.in = dh + l * hs; la.out = dh + (l - 1) * hs; la.act = sh + (l - 1) * hs; la.IN = H; la.OUT = H; la.mat_off = (unsigned)K.wt(l);
     la.kp_log = log2i(H); la.layer = l - 1;
-    hipLaunchKernelGGL((wide_layer_x6_kernel<EPI_BACKWARD>), dim3(grid_l), dim3(kThreadsX), 0, st, la);
+    launch_wide_layer<EPI_BACKWARD>(la, grid_l, st);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;
