@@ -1,27 +1,23 @@
-import ctypes, sys, torch
-import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R, os.path.join(R, "tests"), os.path.join(R, "oracle")]
-import pinn_amd
-from pinn_amd import _lib
-import hip_helpers as hh
-import pinn_oracle as O
-lib = _lib.load()
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _common as hh
+from _common import _lib, lib
 H, nh, N = int(os.environ.get("PINN_H", "256")), 3, 1_000_000
-P = O.init_params([8, H, H, H, 1], seed=1)
-fp = hh.flat_params(P, H, nh).to(hh.dev())
+fp = hh.random_params(H, nh)
 x = torch.rand(N, 8, device=hh.dev())
 PRECS = [int(a) for a in sys.argv[1:]] or [0, 1, 2]
 for prec in PRECS:
     for mode in (0, 1):
         drop = hh.dropout_struct(mode, [0.2] * 4, seed=1, stream_id=2)
-        for _ in range(3): hh.forward(lib, H, nh, fp, x, drop, precision=prec)
+        for _ in range(3): hh.forward(H, nh, fp, x, drop, precision=prec)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10): hh.forward(lib, H, nh, fp, x, drop, precision=prec)
+        for _ in range(10): hh.forward(H, nh, fp, x, drop, precision=prec)
         e1.record(); torch.cuda.synchronize()
         print(f"prec {prec} mode {mode}: forward {e0.elapsed_time(e1)/10:.3f} ms", flush=True)
     out = torch.empty(3, N, device=hh.dev())
-    net = hh.make_net(lib, H, nh, prec)
+    net = hh.make_net(H, nh, prec)
     d = hh.dropout_struct(1, [0.4] * 4, seed=99, stream_id=1000)
     T = 64
     for it in range(2):

@@ -1,19 +1,15 @@
 """Time the phases of pinn_mlp_train_grads at 1e6 rows: python tools/time_train.py [PREC ...]."""
 import ctypes, os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R, os.path.join(R, "tests"), os.path.join(R, "oracle")]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
-import pinn_amd
-from pinn_amd import _lib
-import hip_helpers as hh
-import pinn_oracle as O
-lib = _lib.load()
+import _common as hh
+from _common import _lib, lib
 H, nh, N = 256, 3, 1_000_000
-P = O.init_params([8, H, H, H, 1], seed=1)
-fp = hh.flat_params(P, H, nh).to(hh.dev())
+fp = hh.random_params(H, nh)
 x = torch.rand(N, 8, device=hh.dev()); y = torch.rand(N, device=hh.dev())
 drop = hh.dropout_struct(1, [0.2] * 4, seed=1, stream_id=2)
 for prec in [int(a) for a in sys.argv[1:]] or [0, 1, 2]:
-    net = hh.make_net(lib, H, nh, prec)
+    net = hh.make_net(H, nh, prec)
     wb = lib.pinn_train_workspace_bytes(ctypes.byref(net), N)
     work = torch.empty(wb, dtype=torch.uint8, device=hh.dev())
     grads = torch.empty(fp.numel(), device=hh.dev()); loss = torch.zeros(4, dtype=torch.float64, device=hh.dev())

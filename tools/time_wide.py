@@ -1,20 +1,16 @@
 """Time the wide-net ([8, 1024 x 4, 1], BASELINE config 5) forward, MC-dropout and training-gradient calls."""
 import ctypes, os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R, os.path.join(R, "tests"), os.path.join(R, "oracle")]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
-import pinn_amd
-from pinn_amd import _lib
-import hip_helpers as hh
-import pinn_oracle as O
-lib = _lib.load()
+import _common as hh
+from _common import _lib, lib
 H, nh = 1024, 4
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 M = 8 * H + (nh - 1) * H * H + H + H * H // 2 + H * H // 8 + H // 4
-P = O.init_params([8] + [H] * nh + [1], seed=1)
-fp = hh.flat_params(P, H, nh).to(hh.dev())
+fp = hh.random_params(H, nh)
 x = torch.rand(N, 8, device=hh.dev()); y = torch.rand(N, device=hh.dev())
 drop = hh.dropout_struct(1, [0.2] * (nh + 1), seed=1, stream_id=2)
-net = hh.make_net(lib, H, nh, 2)
+net = hh.make_net(H, nh, 2)
 def ev(fn, reps):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

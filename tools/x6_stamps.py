@@ -1,19 +1,15 @@
 """Diagnostic: per-wave cycle split of the x6 forward (needs a -DPINN_X6_STAMP build loaded via PINN_HIP_LIB)."""
 import ctypes, os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R, os.path.join(R, "tests"), os.path.join(R, "oracle")]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
-import pinn_amd
-from pinn_amd import _lib
-import hip_helpers as hh
-import pinn_oracle as O
-lib = _lib.load()
+import _common as hh
+from _common import _lib, lib
 H, nh, N = 256, 3, 1_000_000
-P = O.init_params([8, H, H, H, 1], seed=1)
-fp = hh.flat_params(P, H, nh).to(hh.dev())
+fp = hh.random_params(H, nh)
 x = torch.rand(N, 8, device=hh.dev())
 drop = hh.dropout_struct(1, [0.2] * 4, seed=1, stream_id=2)
 for _ in range(3):
-    hh.forward(lib, H, nh, fp, x, drop, precision=2)
+    hh.forward(H, nh, fp, x, drop, precision=2)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 32)()
 lib.pinn_x6_debug_read.restype = ctypes.c_int
