@@ -9,6 +9,7 @@
 // residues and the gradient is a sum over all rows, so the tensors come out ~5e-6 of their largest element from the
 // float64 result (torch's fp32 matmul: 3e-7; the parity tolerance on gradients: 2e-4) at half the NS = 3 cost.
 // Same slices / slabs / bias and vector-head sums as wgrad_kernel (pinn_train.hip); layer 0 (IN = 8) stays there.
+#include <cstdlib>
 #include "pinn_x6_core.h"
 #include "pinn_wgrad_args.h"
 
@@ -174,6 +175,141 @@ __global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Deep-prefetch version for the plain layers (no vector-head sums): the fragments of tile t + 2 stream global -> LDS by
+// LDS-DMA into a PRIVATE two-stage ring per wave (no sharing, so no barrier: only a counted vmcnt), tile t + 1 moves
+// LDS -> registers while tile t is split and multiplied.  The register-staged kernel above has one tile (1.9 us of
+// work) between a load and its use -- about one HBM latency -- and stalls on most of them.
+// ---------------------------------------------------------------------------------------
+template <int TI, int TJ, int WI, int WJ, int NS>
+__global__ __launch_bounds__(256, 1) void wgrad_d_kernel(WgradArgs a) {
+  constexpr int kFrags = TI + TJ, kStage = kFrags * 2048;            // bytes per wave and tile: 2 KB per fragment
+  extern __shared__ __attribute__((aligned(1024))) char ring_all[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave >= WI * WJ) return;
+  char* ring = ring_all + wave * 2 * kStage;
+  const int wi = wave / WJ, wj = wave % WJ;
+  const int hh = lane >> 5, i = lane & 31;
+  const int i0 = blockIdx.y * (TI * 32 * WI) + wi * TI * 32, j0 = blockIdx.z * (TJ * 32 * WJ) + wj * TJ * 32;
+  const bool row_sums = wj == 0 && blockIdx.z == 0;
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
+  float bsum[TI];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) bsum[ti] = 0.f;
+
+  const int slice = blockIdx.x;
+  const long long per = (a.t16 + a.n_slices - 1) / a.n_slices;
+  const long long t_begin = slice * per;
+  long long t_end = t_begin + per;
+  if (t_end > a.t16) t_end = a.t16;
+
+  // 2 x kFrags DMA instructions per tile: half q (rows 8 hh + 4 q ..) of fragment f, lane-linear 16 B per lane
+  auto fetch = [&](long long t, int stage) {
+    const float* pP = a.P + ((t * a.OUT + i0 + i) * 16 + 8 * hh);
+    const float* pQ = a.Q + ((t * a.IN + j0 + i) * 16 + 8 * hh);
+    char* st = ring + stage * kStage;
+#pragma unroll
+    for (int f = 0; f < kFrags; ++f) {
+      const float* src = f < TI ? pP + f * 512 : pQ + (f - TI) * 512;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + f * 2048), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + 4), (lptr_t)(st + f * 2048 + 1024), 16, 0, 0);
+    }
+  };
+  auto read = [&](Raw<TI, TJ>& r, int stage) {
+    const char* st = ring + stage * kStage + lane * 16;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      r.a[ti][0] = *reinterpret_cast<const f32x4*>(st + ti * 2048);
+      r.a[ti][1] = *reinterpret_cast<const f32x4*>(st + ti * 2048 + 1024);
+    }
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      r.b[tj][0] = *reinterpret_cast<const f32x4*>(st + (TI + tj) * 2048);
+      r.b[tj][1] = *reinterpret_cast<const f32x4*>(st + (TI + tj) * 2048 + 1024);
+    }
+  };
+  if (t_begin < t_end) {
+    auto clampt = [&](long long t) { return t < t_end ? t : t_end - 1; };
+    Raw<TI, TJ> cur, nxt;
+    fetch(t_begin, 0);
+    fetch(clampt(t_begin + 1), 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kFrags) : "memory");       // tile t_begin has landed
+    read(cur, 0);
+    for (long long t = t_begin; t < t_end; ++t) {
+      const int s0 = (int)((t - t_begin) & 1);
+      // stage s0 (tile t) is in registers: it takes tile t + 2; then tile t + 1 (the other stage) must have landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // ... the LDS reads of `cur` are done
+      fetch(clampt(t + 2), s0);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kFrags) : "memory");
+      read(nxt, s0 ^ 1);
+      Parts<NS> pa[TI], pb[TJ];
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) pa[ti] = split8<NS>(cur.a[ti][0], cur.a[ti][1]);
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) pb[tj] = split8<NS>(cur.b[tj][0], cur.b[tj][1]);
+#pragma unroll
+      for (int tot = NS - 1; tot >= 0; --tot)
+#pragma unroll
+        for (int sa = 0; sa <= tot; ++sa)
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TJ; ++tj)
+              acc[ti][tj] = PINN_MFMA32_BF16(__builtin_bit_cast(bf16x8, pa[ti].p[sa]), __builtin_bit_cast(bf16x8, pb[tj].p[tot - sa]), acc[ti][tj]);
+      if (row_sums) {
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg) bsum[ti] += (cur.a[ti][sg][0] + cur.a[ti][sg][1]) + (cur.a[ti][sg][2] + cur.a[ti][sg][3]);
+      }
+      cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing re-fetches must land before the LDS is released
+  }
+
+  const long long so = (long long)slice * a.slab_stride;
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const int col = j0 + tj * 32 + i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        a.dW[so + (long long)row * a.IN + col] = acc[ti][tj][r];
+      }
+    }
+  if (row_sums) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      const float b = bsum[ti] + __shfl_xor(bsum[ti], 32, 64);
+      if (hh == 0) a.db[so + i0 + ti * 32 + i] = b;
+    }
+  }
+}
+
+template <int TI, int TJ, int WI, int WJ>
+static int launch_d(const WgradArgs& a, int ns, hipStream_t st) {
+  const dim3 grid(a.n_slices, a.OUT / (TI * 32 * WI), a.IN / (TJ * 32 * WJ));
+  const size_t lds = (size_t)WI * WJ * 2 * (TI + TJ) * 2048;
+  auto k3 = wgrad_d_kernel<TI, TJ, WI, WJ, 3>;
+  auto k2 = wgrad_d_kernel<TI, TJ, WI, WJ, 2>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)(ns == 3 ? k3 : k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (ns == 3) hipLaunchKernelGGL(k3, grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(k2, grid, dim3(256), lds, st, a);
+  return PINN_OK;
+}
+
 template <int TI, int TJ, int WI, int WJ>
 static void launch(const WgradArgs& a, int ns, hipStream_t st) {
   const dim3 grid(a.n_slices, a.OUT / (TI * 32 * WI), a.IN / (TJ * 32 * WJ));
@@ -189,6 +325,8 @@ int dispatch_wgrad_x6(const WgradArgs& a, int ns, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int to = a.OUT / 32, ti = a.IN / 32;
   if (a.Q == nullptr || a.IN % 32 || a.OUT % 32) return PINN_E_ARCH;
+  static const bool direct = getenv("PINN_WGRAD_DIRECT") != nullptr;     // measurement: the register-staged kernel everywhere
+  if (!direct && !a.dvq && !a.dvr && to % 8 == 0 && ti % 8 == 0) return launch_d<4, 4, 2, 2>(a, ns, st);   // plain layers: deep prefetch
   if (to == 8 && ti == 8) launch<4, 4, 2, 2>(a, ns, st);
   else if (to == 4 && ti == 8) launch<2, 4, 2, 2>(a, ns, st);
   else if (to == 2 && ti == 4) launch<1, 2, 2, 2>(a, ns, st);
