@@ -264,3 +264,24 @@ def test_wide_model_surface():
     assert np.all(np.isfinite(pm)) and np.all(au > 0) and np.all(eu > 0)
     with pytest.raises(Exception):
         m.dnn.set_precision("fp32"); m.predict(ds[0], ds[4])          # wide nets: x6 arithmetic only
+
+
+def test_forward_wide_multi_chunk(lib):
+    """More rows than one scratch chunk (65 536): rows on both sides of the chunk edge against the oracle."""
+    import hip_helpers as hh
+    H, nh, N = 512, 1, 65536 + 300
+    P = O.init_params([8, H, 1], seed=9)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(N, 8, generator=g) * 2 - 1
+    fp, xd = hh.flat_params(P, H, nh).to(hh.dev()), x.to(hh.dev())
+    pl = [0.2] * (nh + 1)
+    seed, stream, row0 = 7, 3, 500
+    drop = hh.dropout_struct(1, pl, seed=seed, stream_id=stream, row_offset=row0)
+    u, lv = hh.forward(lib, H, nh, fp, xd, drop, precision=2)
+    u, lv = u.cpu().numpy(), lv.cpu().numpy()
+    for lo, hi in ((0, 200), (65436, N)):
+        masks = O.philox_masks_for_net(seed, stream, row0 + lo, hi - lo, H, nh, pl)
+        with torch.no_grad():
+            uf, lvf = O.mlp_forward(P, x[lo:hi], pl, masks)
+        np.testing.assert_allclose(u[lo:hi], uf.numpy().reshape(-1), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(lv[lo:hi], lvf.numpy().reshape(-1), rtol=1e-5, atol=1e-5)

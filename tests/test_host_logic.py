@@ -75,3 +75,13 @@ def test_dp_shard_bounds_cover_rows():
         for g in (1, 2, 3, 8):
             b = [dp.shard_bounds(n, r, g) for r in range(g)]
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(g - 1))
+
+
+def test_check_arch_widths():
+    """Fused widths, wide widths (layer-by-layer kernels) and rejected ones."""
+    from pinn_amd import layout
+    assert layout.check_arch([8, 256, 256, 256, 1]) == (8, 256, 3)
+    assert layout.check_arch([8, 1024, 1024, 1024, 1024, 1]) == (8, 1024, 4)
+    for bad in ([8, 384, 1], [8, 256, 128, 1], [7, 256, 1], [8, 256, 2], [8] + [256] * 9 + [1]):
+        with pytest.raises(ValueError):
+            layout.check_arch(bad)
