@@ -64,8 +64,11 @@ void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st
   hipLaunchKernelGGL(pack_x6_kernel, dim3(64, n), dim3(256), 0, st, d_params, (__bf16*)net->d_packed, jobs);
 }
 
-template <int H, bool MC, bool kBits>
-__global__ __launch_bounds__(kThreadsX, 2) void mlp_x6_kernel(FwdArgs a, const __bf16* packed) {
+// WAVES = 8: 128-row tiles, two waves per SIMD.  WAVES = 4 (small row counts, fewer tiles than CUs): 64-row tiles, one
+// wave per SIMD -- twice the CUs busy and no wave shares its SIMD's matrix core, so a tile finishes in about half the time.
+template <int H, bool MC, bool kBits, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp_x6_kernel(FwdArgs a, const __bf16* packed) {
+  constexpr int kThreadsX = WAVES * 64, kTileRowsX = WAVES * 16;
   // one LDS block, small things FIRST: a ds instruction's immediate offset is 16 bits, and every per-layer bias /
   // head-weight address beyond 64 KB would need its own address register (hipcc hoists them all: spills)
   constexpr int kSmallBytes = kMaxSmall * 4, kW0Bytes = 8 * kW0Stride * 4;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(kThreadsX, 2) void mlp_x6_kernel(FwdArgs a, const _
   Pipe6 pipe;
   pipe.packed = (const char*)packed; pipe.copy_bytes = (unsigned)(K.total() * 2); pipe.lds = lds_w;
   pipe.init(threadIdx.x);
-  pipe.prime<clog2(H)>(first_mat<H>(K));
+  pipe.prime<clog2(H), WAVES>(first_mat<H>(K));
 #ifdef PINN_X6_STAMP
   for (int k = 0; k < 4; ++k) pipe.seg[k] = 0;
   pipe.last = stamp();
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(kThreadsX, 2) void mlp_x6_kernel(FwdArgs a, const _
     if (!MC) {
       float u, z;
       PINN_STAMP(pipe, 3);
-      forward_pass_x6<H, kBits>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z);
+      forward_pass_x6<H, kBits, false, WAVES>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z);
       if (valid && lane < 16) {
         a.o0[lrow] = u;
         a.o1[lrow] = logf(softplus_f32(z) + 1e-6f);
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(kThreadsX, 2) void mlp_x6_kernel(FwdArgs a, const _
         c.pass = (unsigned)(t < 0 ? 0 : t);
         float u, z;
         PINN_STAMP(pipe, 3);
-        forward_pass_x6<H, kBits>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z);
+        forward_pass_x6<H, kBits, false, WAVES>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z);
         if (t < 0) {
           u_eval = u;
         } else {
@@ -156,11 +159,18 @@ int launch_forward_x6(const pinn_net_t* net, const FwdArgs& a, bool mc, void* st
   hipStream_t st = (hipStream_t)stream;
   (void)hipGetLastError();
   launch_pack_x6(net, a.params, st);
-  const long long n_tiles = (a.n_rows + kTileRowsX - 1) / kTileRowsX;
-  const int grid = (int)(n_tiles < cu_count_x() ? n_tiles : cu_count_x());
+  const int cus = cu_count_x();
+  const long long t128 = (a.n_rows + 127) / 128;
+  const bool small_n = 2 * t128 <= cus;                    // 64-row tiles still fit one per CU
+  const long long n_tiles = small_n ? (a.n_rows + 63) / 64 : t128;
+  const int grid = (int)(n_tiles < cus ? n_tiles : cus);
   const __bf16* packed = (const __bf16*)net->d_packed;
   const bool bits = a.drop.mode == PINN_DROP_BITS;
-#define PINN_LAUNCH_X(HH, MCC, BB) hipLaunchKernelGGL((mlp_x6_kernel<HH, MCC, BB>), dim3(grid), dim3(kThreadsX), 0, st, a, packed)
+#define PINN_LAUNCH_X(HH, MCC, BB)                                                                                              \
+  do {                                                                                                                          \
+    if (small_n) hipLaunchKernelGGL((mlp_x6_kernel<HH, MCC, BB, 4>), dim3(grid), dim3(256), 0, st, a, packed);                  \
+    else hipLaunchKernelGGL((mlp_x6_kernel<HH, MCC, BB, 8>), dim3(grid), dim3(512), 0, st, a, packed);                          \
+  } while (0)
   if (net->hidden == 256) {
     if (mc) { if (bits) PINN_LAUNCH_X(256, true, true); else PINN_LAUNCH_X(256, true, false); }
     else    { if (bits) PINN_LAUNCH_X(256, false, true); else PINN_LAUNCH_X(256, false, false); }

@@ -103,9 +103,9 @@ struct Pipe6 {
   }
   // this wave's j-th piece of K-group g of matrix m (row stride 2^KP_LOG) into buffer buf.  Branch-free: a wave whose
   // j-th piece does not exist (small matrices) fetches piece p - n again instead -- same bytes to the same place.
-  template <int KP_LOG>
+  template <int KP_LOG, int WAVES = 8>
   __device__ __forceinline__ void piece(const Mat& m, int g, int j, int buf) {
-    int p = wave + 8 * j;
+    int p = wave + WAVES * j;
     const int n = 3 << m.nrb_log;
     p = p < n ? p : p - n;
     asm volatile("" : "+s"(p));   // or hipcc precomputes every piece's 64-bit address outside the row loop (spills)
@@ -116,12 +116,12 @@ struct Pipe6 {
     __builtin_amdgcn_global_load_lds((gptr_t)(packed + goff + voff), (lptr_t)dst, 16, 0, 0);
   }
   // slab 0 of the sequence
-  template <int KP_LOG>
+  template <int KP_LOG, int WAVES = 8>
   __device__ __forceinline__ void prime(const Mat& first) {
     par = 0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
-      if (8 * j < (3 << first.nrb_log)) piece<KP_LOG>(first, 0, j, 0);
+    for (int j = 0; j < 48 / WAVES; ++j)
+      if (WAVES * j < (3 << first.nrb_log)) piece<KP_LOG, WAVES>(first, 0, j, 0);
     __syncthreads();           // (drains the DMA: vmcnt(0) + barrier)
   }
   __device__ __forceinline__ const char* cur() const { return lds + par * kSlabBytes; }
@@ -337,10 +337,10 @@ __device__ __forceinline__ void prep_micro(Prep& s, f32x4& v0, f32x4& v1, const 
 // whose raw values are this layer's acc[0], acc[1] -- final once the last slab's first tile pair is through, so
 // those steps sit in slots >= 1.  KPM / KPN: log2 row stride of this / the next matrix; NPM / NPN: (an upper bound
 // of) their 1-KB pieces per slab.
-template <int NG, int NTOUT, int KPM, int KPN, int NPM, int NPN, bool kHasOut, typename FI, typename FO>
+template <int NG, int NTOUT, int KPM, int KPN, int NPM, int NPN, bool kHasOut, int WAVES = 8, typename FI, typename FO>
 __device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], Pipe6& pipe, const Mat& mine, const Mat& next, int lane, Frag3& cur, Prep& st,
                                          FI&& prep_in, FO&& prep_out) {
-  constexpr int kSlots = NTOUT / 2, kPerDma = (6 + kSlots - 1) / kSlots;
+  constexpr int kSlots = NTOUT / 2, kPerDma = (48 / WAVES + kSlots - 1) / kSlots;      // <= 48 / WAVES pieces per wave and slab
   // VALU chunks: one per tile (NTOUT per slab).  The six micro-steps of the next group go to chunks
   // kFirst + k * (NTOUT - kFirst) / 6; acc[0], acc[1] (the next layer's group 0) are final from chunk 2 on.
   constexpr int kFirst = kHasOut ? 2 : 0, kAvail = NTOUT - kFirst;
@@ -352,9 +352,9 @@ __device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], Pipe6& pipe, const
       static_for<kPerDma>([&](auto qc) {
         constexpr int j = decltype(slotc)::value * kPerDma + decltype(qc)::value;
         if constexpr (g + 1 < NG) {
-          if constexpr (8 * j < NPM) pipe.piece<KPM>(mine, g + 1, j, pipe.par ^ 1);
+          if constexpr (WAVES * j < NPM) pipe.piece<KPM, WAVES>(mine, g + 1, j, pipe.par ^ 1);
         } else {
-          if constexpr (8 * j < NPN) pipe.piece<KPN>(next, 0, j, pipe.par ^ 1);
+          if constexpr (WAVES * j < NPN) pipe.piece<KPN, WAVES>(next, 0, j, pipe.par ^ 1);
         }
       });
     };
@@ -397,7 +397,7 @@ struct StashX {
 
 // One forward pass for this wave's 16 rows (x6 matrix math).  Returns (u, z); TRAIN: activations go to the stash,
 // v2 = the tanh'ed last variance block(s), and the weight stream continues with the backward pass's first matrix.
-template <int H, bool kBits, bool TRAIN = false>
+template <int H, bool kBits, bool TRAIN = false, int WAVES = 8>
 __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* smallp, const ParamLayout& L, Pipe6& pipe,
                                                 const DropDev& d, const RowCtx& c, const f32x4& xa, const f32x4& xb, float& u, float& z,
                                                 const StashX* sx = nullptr, f32x4* v2_out = nullptr) {
@@ -429,7 +429,7 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
     const Mat mine{(unsigned)K.w(l), clog2(H / 16)}, next = last ? m_v0 : Mat{(unsigned)K.w(l + 1), clog2(H / 16)};
     float* sp_in = TRAIN ? sx->act(l - 1, H, lane) : nullptr;
     float* sp_out = TRAIN ? sx->act(l, H, lane) : nullptr;
-    layer_x6<NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true>(
+    layer_x6<NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true, WAVES>(
         acc, pipe, mine, next, lane, cur, st,
         [&](auto gc, auto kc) {
           constexpr int g = decltype(gc)::value;
@@ -447,7 +447,7 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
     const LayerDrop ld_in = layer_drop(d, c.mode, ll), ld_out = layer_drop(d, c.mode, L.nh);
     float* sp_in = TRAIN ? sx->act(ll, H, lane) : nullptr;
     float* sp_out = TRAIN ? tiled_ptr(sx->v1, sx->t16, H / 2, lane) : nullptr;
-    layer_x6<NP, NT2, KPW, KPV1, 3 * H / 32, 3 * H / 64, true>(
+    layer_x6<NP, NT2, KPW, KPV1, 3 * H / 32, 3 * H / 64, true, WAVES>(
         v1, pipe, m_v0, m_v1, lane, cur, st,
         [&](auto gc, auto kc) {
           constexpr int g = decltype(gc)::value;
@@ -471,9 +471,9 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
       // the backward pass starts with Wv1^T: [H/2][H/4], row stride padded to 64
       constexpr int KPT1 = clog2((H / 4 + 63) & ~63);
       const Mat m_t1{(unsigned)K.wv1t(), clog2(H / 32)};
-      layer_x6<NP / 2, NT4, KPV1, KPT1, 3 * H / 64, 3 * H / 32, false>(v2, pipe, m_v1, m_t1, lane, cur, st, prep_in, [&](auto) {});
+      layer_x6<NP / 2, NT4, KPV1, KPT1, 3 * H / 64, 3 * H / 32, false, WAVES>(v2, pipe, m_v1, m_t1, lane, cur, st, prep_in, [&](auto) {});
     } else {
-      layer_x6<NP / 2, NT4, KPV1, KPW, 3 * H / 64, 3 * H / 16, false>(v2, pipe, m_v1, first_mat<H>(K), lane, cur, st, prep_in, [&](auto) {});
+      layer_x6<NP / 2, NT4, KPV1, KPW, 3 * H / 64, 3 * H / 16, false, WAVES>(v2, pipe, m_v1, first_mat<H>(K), lane, cur, st, prep_in, [&](auto) {});
     }
   }
   float zp = 0.0f;
@@ -532,7 +532,7 @@ __device__ __forceinline__ void bprep_micro(Prep& s, f32x4& d0, f32x4& d1, const
 // Backward chain of this wave's 16 rows: d pre-activations of every layer to the stash.  du, dz = d loss / d (u, z);
 // v2 = tanh'ed last variance blocks.  The weight stream arrives positioned on Wv1^T and leaves on the forward pass's
 // first matrix.
-template <int H>
+template <int H, int WAVES = 8>
 __device__ __forceinline__ void backward_pass_x6(const float* smallp, const ParamLayout& L, Pipe6& pipe, const DropDev& d, int mode,
                                                  const StashX& sx, const StashRing& ring, int lane, float du, float dz, f32x4* v2) {
   constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32;
@@ -579,7 +579,7 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     const LayerDrop ldv = layer_drop(d, mode, nh);
     const float scale = ldv.scale, inv_scale = 1.0f / scale;
     float* dsp = tiled_ptr(sx.dv1, sx.t16, H / 2, lane);
-    layer_x6<NG1, NT2, KPT1, KPT0, 3 * H / 32, 3 * H / 16, true>(
+    layer_x6<NG1, NT2, KPT1, KPT0, 3 * H / 32, 3 * H / 16, true, WAVES>(
         dpv1, pipe, m_t1, m_t0, lane, cur, st,
         [&](auto gc, auto kc) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
@@ -608,7 +608,7 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     float* dsp = tiled_ptr(sx.dv1, sx.t16, H / 2, lane);
     float* dsp_o = sx.dact(nh - 1, H, lane);
     const Mat next = nh > 1 ? Mat{(unsigned)K.wt(nh - 1), clog2(H / 16)} : m_first;
-    layer_x6<NP / 2, NT, KPT0, KPW, 3 * H / 16, 3 * H / 16, true>(
+    layer_x6<NP / 2, NT, KPT0, KPW, 3 * H / 16, 3 * H / 16, true, WAVES>(
         dh, pipe, m_t0, next, lane, cur, st,
         [&](auto gc, auto kc) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
@@ -635,7 +635,7 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     float* dsp_o = sx.dact(l - 1, H, lane);
     const int base = NP / 2 + (nh - 1 - l) * NP;           // stash block index of this layer's group 0
     const Mat mine{(unsigned)K.wt(l), clog2(H / 16)}, next = l > 1 ? Mat{(unsigned)K.wt(l - 1), clog2(H / 16)} : m_first;
-    layer_x6<NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true>(
+    layer_x6<NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true, WAVES>(
         acc, pipe, mine, next, lane, cur, st,
         [&](auto gc, auto kc) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;

@@ -19,8 +19,10 @@ struct TrainArgsX {
   TrainBuffers b;
 };
 
-template <int H, bool kBits>
-__global__ __launch_bounds__(kThreadsX, 2) void train_chain_x6_kernel(TrainArgsX a, const __bf16* packed) {
+// WAVES: 8 = 128-row tiles, two waves per SIMD; 4 = 64-row tiles, one wave per SIMD (small row counts, see mlp_x6_kernel)
+template <int H, bool kBits, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_chain_x6_kernel(TrainArgsX a, const __bf16* packed) {
+  constexpr int kThreadsX = WAVES * 64, kTileRowsX = WAVES * 16;
   constexpr int NT4 = H / 64;
   constexpr int kSmallBytes = kMaxSmall * 4, kW0Bytes = 8 * kW0Stride * 4, kRingBytes = 8 * 2 * 2048, kRedBytes = 8 * kLossTermsX * 8;
   constexpr int kSlabAt = (kSmallBytes + kW0Bytes + kRedBytes + kRingBytes + 1023) & ~1023;
@@ -47,16 +49,16 @@ __global__ __launch_bounds__(kThreadsX, 2) void train_chain_x6_kernel(TrainArgsX
   Pipe6 pipe;
   pipe.packed = (const char*)packed; pipe.copy_bytes = (unsigned)(K.total() * 2); pipe.lds = lds_w;
   pipe.init(threadIdx.x);
-  pipe.prime<clog2(H)>(first_mat<H>(K));
+  pipe.prime<clog2(H), WAVES>(first_mat<H>(K));
 
   const int lane = threadIdx.x & 63, wave = pipe.wave, kq = lane >> 4;
   const StashRing ring{ring_lds + wave * 4096, lane};
   const float inv_n = (float)(1.0 / (double)a.n_global);
   float s_nll = 0.f, s_abs = 0.f, s_mse = 0.f, s_du = 0.f, s_dz = 0.f;
 
-  const long long n_tiles = (a.n_rows + kTileRowsX - 1) / kTileRowsX;
+  const long long n_tiles = (a.n_rows + 127) / 128 * (128 / kTileRowsX);      // whole 128-row stash tiles
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const long long t16 = tile * 8 + wave;
+    const long long t16 = tile * WAVES + wave;
     const long long lrow = t16 * 16 + (lane & 15);
     const bool valid = lrow < a.n_rows;
     const long long srow = valid ? lrow : a.n_rows - 1;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(kThreadsX, 2) void train_chain_x6_kernel(TrainArgsX
     // ------------------------------------------------------------------ forward (activations stashed)
     float u, z;
     f32x4 v2[NT4];
-    forward_pass_x6<H, kBits, true>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z, &sx, v2);
+    forward_pass_x6<H, kBits, true, WAVES>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z, &sx, v2);
 
     // ------------------------------------------------------------------ aleatoric_loss (01:916-927) and its gradient
     float du = 0.f, dz = 0.f;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(kThreadsX, 2) void train_chain_x6_kernel(TrainArgsX
 
     // ------------------------------------------------------------------ backward chain
 #ifndef PINN_X6_NOBWD
-    backward_pass_x6<H>(small, L, pipe, a.drop, a.drop.mode, sx, ring, lane, du, dz, v2);
+    backward_pass_x6<H, WAVES>(small, L, pipe, a.drop, a.drop.mode, sx, ring, lane, du, dz, v2);
 #endif
   }
 
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(kThreadsX, 2) void train_chain_x6_kernel(TrainArgsX
   if (threadIdx.x < kLossTermsX) {
     double t = 0.0;
     if (threadIdx.x < 5)
-      for (int w = 0; w < 8; ++w) t += red[w][threadIdx.x];
+      for (int w = 0; w < WAVES; ++w) t += red[w][threadIdx.x];
     a.b.loss_part[(long long)blockIdx.x * kLossTermsX + threadIdx.x] = t;
   }
 }
@@ -139,18 +141,22 @@ int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const fl
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
   if (cus <= 0) cus = 256;
-  const long long n_tiles = (n_rows + kTileRowsX - 1) / kTileRowsX;
+  // the stash is padded to whole 128-row tiles: the 64-row kernel covers them too (two tiles each)
+  const long long t128 = (n_rows + 127) / 128;
+  const bool small_n = 2 * t128 <= cus;
+  const long long n_tiles = small_n ? 2 * t128 : t128;
   const int grid = (int)(n_tiles < cus ? n_tiles : cus);
   *grid_out = grid;
   const __bf16* packed = (const __bf16*)net->d_packed;
   const bool bits = drop.mode == PINN_DROP_BITS;
-  if (net->hidden == 256) {
-    if (bits) hipLaunchKernelGGL((train_chain_x6_kernel<256, true>), dim3(grid), dim3(kThreadsX), 0, st, a, packed);
-    else hipLaunchKernelGGL((train_chain_x6_kernel<256, false>), dim3(grid), dim3(kThreadsX), 0, st, a, packed);
-  } else {
-    if (bits) hipLaunchKernelGGL((train_chain_x6_kernel<128, true>), dim3(grid), dim3(kThreadsX), 0, st, a, packed);
-    else hipLaunchKernelGGL((train_chain_x6_kernel<128, false>), dim3(grid), dim3(kThreadsX), 0, st, a, packed);
-  }
+#define PINN_LAUNCH_T(HH, BB)                                                                                                   \
+  do {                                                                                                                          \
+    if (small_n) hipLaunchKernelGGL((train_chain_x6_kernel<HH, BB, 4>), dim3(grid), dim3(256), 0, st, a, packed);               \
+    else hipLaunchKernelGGL((train_chain_x6_kernel<HH, BB, 8>), dim3(grid), dim3(512), 0, st, a, packed);                       \
+  } while (0)
+  if (net->hidden == 256) { if (bits) PINN_LAUNCH_T(256, true); else PINN_LAUNCH_T(256, false); }
+  else { if (bits) PINN_LAUNCH_T(128, true); else PINN_LAUNCH_T(128, false); }
+#undef PINN_LAUNCH_T
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;
 }

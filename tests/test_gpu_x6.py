@@ -18,8 +18,10 @@ def lib():
     return _lib.load()
 
 
+# row counts on both sides of the kernel choice: <= 128 * (#CU / 2) rows run the 4-wave / 64-row-tile kernels, more the
+# 8-wave / 128-row-tile ones
 @pytest.mark.parametrize("H,nh,N,mode", [(256, 3, 1000, 0), (256, 3, 777, 1), (128, 3, 333, 1), (128, 1, 64, 1), (256, 5, 130, 1),
-                                         (256, 3, 1, 0), (128, 2, 4097, 0)])
+                                         (256, 3, 1, 0), (128, 2, 4097, 0), (256, 3, 20001, 1), (128, 2, 33000, 1)])
 def test_forward_x6(lib, H, nh, N, mode):
     import hip_helpers as hh
     from pinn_amd import synth
@@ -60,10 +62,11 @@ def test_forward_x6_injected_masks(lib):
     np.testing.assert_allclose(lv.cpu().numpy(), lvf.numpy().reshape(-1), rtol=1e-5, atol=1e-5)
 
 
-def test_mc_dropout_x6(lib):
+@pytest.mark.parametrize("N,T", [(300, 16), (17000, 2)])
+def test_mc_dropout_x6(lib, N, T):
     import hip_helpers as hh
     from pinn_amd import _lib, synth
-    H, nh, N, T, p = 256, 3, 300, 16, 0.4
+    H, nh, p = 256, 3, 0.4
     P = O.init_params([8, H, H, H, 1], seed=1)
     x = synth.make_dataset(N, (), seed=2)[0]
     out = torch.empty(3, N, device=hh.dev())
@@ -92,7 +95,7 @@ def _check_grads(got_flat, want_list, H, nh, rtol, atol_scale=1e-6):
 
 @pytest.mark.parametrize("prec", [2, 3])
 @pytest.mark.parametrize("H,nh,N,mode", [(256, 3, 1000, 1), (128, 3, 333, 1), (256, 2, 129, 0), (128, 4, 4096, 1), (256, 1, 64, 1),
-                                         (128, 1, 200, 1)])
+                                         (128, 1, 200, 1), (256, 3, 17001, 1), (128, 2, 20000, 1)])
 def test_train_grads_x6_vs_oracle_autograd(lib, H, nh, N, mode, prec):
     """Training step with the x6 chain (forward + NLL + backward) and the split-bf16 weight-gradient kernels (prec 2:
     three parts / six products; prec 3 = PINN_PREC_F32X6_G3: two parts / three products): loss and all 14 gradient

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import _common as hh
 from _common import _lib, lib
-H, nh, N = 256, 3, 1_000_000
+H, nh, N = 256, 3, int(os.environ.get("PINN_N", "1000000"))
 fp = hh.random_params(H, nh)
 x = torch.rand(N, 8, device=hh.dev()); y = torch.rand(N, device=hh.dev())
 drop = hh.dropout_struct(1, [0.2] * 4, seed=1, stream_id=2)
