@@ -1,5 +1,6 @@
 // pinn_x6.hip -- fp32-accurate forward / MC-dropout kernels on the bf16 matrix cores
 // (pinn_net_t.precision = PINN_PREC_F32X6).  See pinn_x6_core.h.
+#include <cstdlib>
 #include "pinn_x6_core.h"
 
 namespace pinn {
@@ -161,7 +162,8 @@ int launch_forward_x6(const pinn_net_t* net, const FwdArgs& a, bool mc, void* st
   launch_pack_x6(net, a.params, st);
   const int cus = cu_count_x();
   const long long t128 = (a.n_rows + 127) / 128;
-  const bool small_n = 2 * t128 <= cus;                    // 64-row tiles still fit one per CU
+  static const bool force8 = getenv("PINN_X6_WAVES8") != nullptr;     // measurement: always the 8-wave kernels
+  const bool small_n = !force8 && 2 * t128 <= cus;           // 64-row tiles still fit one per CU
   const long long n_tiles = small_n ? (a.n_rows + 63) / 64 : t128;
   const int grid = (int)(n_tiles < cus ? n_tiles : cus);
   const __bf16* packed = (const __bf16*)net->d_packed;

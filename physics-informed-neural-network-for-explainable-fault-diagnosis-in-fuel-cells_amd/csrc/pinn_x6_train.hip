@@ -2,6 +2,7 @@
 // matrix products on the bf16 matrix cores (pinn_net_t.precision = PINN_PREC_F32X6; see pinn_x6_core.h).
 // Same stash layout and outputs as train_chain_kernel (pinn_train.hip): the weight-gradient and finalize
 // kernels that follow are shared.
+#include <cstdlib>
 #include "pinn_x6_core.h"
 
 namespace pinn {
@@ -143,7 +144,8 @@ int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const fl
   if (cus <= 0) cus = 256;
   // the stash is padded to whole 128-row tiles: the 64-row kernel covers them too (two tiles each)
   const long long t128 = (n_rows + 127) / 128;
-  const bool small_n = 2 * t128 <= cus;
+  static const bool force8 = getenv("PINN_X6_WAVES8") != nullptr;     // measurement: always the 8-wave kernels
+  const bool small_n = !force8 && 2 * t128 <= cus;           // 64-row tiles still fit one per CU
   const long long n_tiles = small_n ? 2 * t128 : t128;
   const int grid = (int)(n_tiles < cus ? n_tiles : cus);
   *grid_out = grid;
