@@ -46,11 +46,11 @@ __device__ __forceinline__ void piece_rt(Pipe6& pipe, unsigned off, int kp_log, 
   const int n = 3 << nrb_log;
   p = p < n ? p : p - n;
   asm volatile("" : "+s"(p));
-  const unsigned voff = ((pipe.lane_row << kp_log) << 1) + pipe.lane_kq8;
+  const unsigned voff = (pipe.lane_row2 << kp_log) + pipe.lane_kq8;
   const int copy = p >> nrb_log, rb = p & ((1 << nrb_log) - 1);
-  const unsigned long long goff = (unsigned long long)copy * pipe.copy_bytes + 2ull * (off + ((unsigned)(rb * 16) << kp_log));
+  const unsigned soff = (unsigned)copy * pipe.copy_bytes + 2u * (off + ((unsigned)(rb * 16) << kp_log));
   char* dst = pipe.lds + buf * kSlabBytes + copy * (kSlabBytes / 3) + rb * 1024;
-  __builtin_amdgcn_global_load_lds((gptr_t)(pipe.packed + goff + voff), (lptr_t)dst, 16, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(pipe.rsrc, (lptr_t)dst, 16, voff, soff, 0, 0);
 }
 
 // kNT accumulator blocks = 16 kNT output features per pass over the K-groups: 16 (256 features, half the input
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
   constexpr int kSlabAt = (kRingBytes + 1023) & ~1023;
   __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * kSlabBytes];
   Pipe6 pipe;
-  pipe.packed = a.packed; pipe.copy_bytes = a.copy_bytes; pipe.lds = smem + kSlabAt;
-  pipe.init(threadIdx.x);
+  pipe.lds = smem + kSlabAt;
+  pipe.init(a.packed, a.copy_bytes, threadIdx.x);
   const int lane = threadIdx.x & 63, wave = pipe.wave, kq = lane >> 4;
   const StashRing ring{smem + wave * 4096, lane};
   const int NG = a.IN / 32, nob = a.OUT / kOB;
@@ -85,8 +85,7 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
     fetch(0);
     fetch(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    Prep st;
-    Frag3 cur;
+    Frag3 cur, nxt;
     static_for<4>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       split_pair<r>(ring.read(0, 0, r), ring.read(0, 1, r), cur);
@@ -122,12 +121,12 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
           constexpr int ci = decltype(cc)::value, every = kNT / 4;
           if constexpr (ci % every == every - 1) {
             constexpr int r = ci / every;
-            split_pair<r>(ring.read(gb & 1, 0, r), ring.read(gb & 1, 1, r), st.out);
+            split_pair<r>(ring.read(gb & 1, 0, r), ring.read(gb & 1, 1, r), nxt);
           }
         };
         slab_mfma<kNT>(acc, cur, pipe.cur(), lane, vchunk, dma);
         pipe.advance();
-        cur = st.out;
+        cur = nxt;
       }
       // ---- epilogue of these 128 output features
       float* out_tile = a.out + (t16 * a.OUT + ob * kOB + 4 * kq) * 16 + (lane & 15);

@@ -93,8 +93,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp_x6_kernel(FwdArgs a
     __syncthreads();
   }
   Pipe6 pipe;
-  pipe.packed = (const char*)packed; pipe.copy_bytes = (unsigned)(K.total() * 2); pipe.lds = lds_w;
-  pipe.init(threadIdx.x);
+  pipe.lds = lds_w;
+  pipe.init(packed, (unsigned)(K.total() * 2), threadIdx.x);
   pipe.prime<clog2(H), WAVES>(first_mat<H>(K));
 #ifdef PINN_X6_STAMP
   for (int k = 0; k < 4; ++k) pipe.seg[k] = 0;

@@ -89,16 +89,21 @@ struct Pipe6 {
 #ifdef PINN_X6_STAMP
   unsigned long long seg[4], last;
 #endif
-  const char* packed;        // copy 0 (bytes); copies 1, 2 follow at +copy_bytes
+  __amdgpu_buffer_rsrc_t rsrc;   // the packed weights as a raw buffer: copy 0 at byte 0, copies 1, 2 at +copy_bytes
   unsigned copy_bytes;
   char* lds;                 // 2 x kSlabBytes
   int par, wave;             // buffer holding the current slab; wave index (uniform)
-  unsigned lane_row, lane_kq8;   // (lane >> 2), 16 B * ((lane & 3) ^ swz(lane >> 2))
+  unsigned lane_row2, lane_kq8;  // 2 * (lane >> 2), 16 B * ((lane & 3) ^ swz(lane >> 2))
 
-  __device__ __forceinline__ void init(int tid) {
+  // A piece is one buffer_load_dwordx4 ... lds: the resource and the piece's byte offset (soffset) are scalar, the
+  // per-lane part is one 32-bit VALU op.  (With a flat global address every piece cost two 64-bit multiply-adds and
+  // two 64-bit adds on the VALU -- a fifth of the vector issue time of the kernels' main loops.)
+  __device__ __forceinline__ void init(const void* packed, unsigned copy_bytes_, int tid) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(packed), 0, 0x7FFFFFFF, 0x00020000);
+    copy_bytes = __builtin_amdgcn_readfirstlane(copy_bytes_);      // (hipcc otherwise keeps it in a VGPR: waterfall loops)
     wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    lane_row = lane >> 2;
+    lane_row2 = (unsigned)(lane >> 2) << 1;
     lane_kq8 = (unsigned)(((lane & 3) ^ swz(lane >> 2)) << 4);
   }
   // this wave's j-th piece of K-group g of matrix m (row stride 2^KP_LOG) into buffer buf.  Branch-free: a wave whose
@@ -108,12 +113,12 @@ struct Pipe6 {
     int p = wave + WAVES * j;
     const int n = 3 << m.nrb_log;
     p = p < n ? p : p - n;
-    asm volatile("" : "+s"(p));   // or hipcc precomputes every piece's 64-bit address outside the row loop (spills)
-    const unsigned voff = ((lane_row << KP_LOG) << 1) + lane_kq8;          // bytes, per lane
+    asm volatile("" : "+s"(p));   // or hipcc precomputes every piece's offset outside the row loop (register pressure)
+    const unsigned voff = (lane_row2 << KP_LOG) + lane_kq8;                // bytes, per lane
     const int copy = p >> m.nrb_log, rb = p & ((1 << m.nrb_log) - 1);
-    const unsigned long long goff = (unsigned long long)copy * copy_bytes + 2ull * (m.off + 32u * (unsigned)g + ((unsigned)(rb * 16) << KP_LOG));
+    const unsigned soff = (unsigned)copy * copy_bytes + 2u * (m.off + 32u * (unsigned)g + ((unsigned)(rb * 16) << KP_LOG));
     char* dst = lds + buf * kSlabBytes + copy * (kSlabBytes / 3) + rb * 1024;
-    __builtin_amdgcn_global_load_lds((gptr_t)(packed + goff + voff), (lptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, voff, soff, 0, 0);
   }
   // slab 0 of the sequence
   template <int KP_LOG, int WAVES = 8>
@@ -261,19 +266,21 @@ __device__ __forceinline__ void layer_input_lds(f32x4 (&acc)[NTOUT], const float
 // 2 .. 5 = register r = k - 2 of both blocks: tanh, dropout, 3-way split (and the predict head's dot).
 // ---------------------------------------------------------------------------------------
 struct Prep {
-  unsigned c0, c1, c2, c3, k0, k1;   // Philox state between micro-steps 0 and 1
+  unsigned c0, c1, c2, c3;   // Philox counter between micro-steps 0 and 1
   unsigned keep;
-  Frag3 out;
+  Frag3 buf[2];      // fragments of the group in the MFMAs / of the group being prepared, alternating (static parity)
 };
-__device__ __forceinline__ void philox_rounds5(Prep& s) {
+// Rounds R0 .. R0 + 4.  The round keys are wave-uniform (seed + round * Weyl constant): they stay on the scalar unit,
+// and each counter update is one three-input XOR (v_bitop3_b32, truth table 0x96).
+template <int R0>
+__device__ __forceinline__ void philox_rounds5(Prep& s, unsigned seed_lo, unsigned seed_hi) {
 #pragma unroll
-  for (int r = 0; r < 5; ++r) {
+  for (int r = R0; r < R0 + 5; ++r) {
     const unsigned long long p0 = (unsigned long long)0xD2511F53u * s.c0;
     const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * s.c2;
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ s.c1 ^ s.k0;
-    const unsigned n2 = (unsigned)(p0 >> 32) ^ s.c3 ^ s.k1;
+    const unsigned n0 = __builtin_amdgcn_bitop3_b32((unsigned)(p1 >> 32), s.c1, seed_lo + (unsigned)r * 0x9E3779B9u, 0x96);
+    const unsigned n2 = __builtin_amdgcn_bitop3_b32((unsigned)(p0 >> 32), s.c3, seed_hi + (unsigned)r * 0xBB67AE85u, 0x96);
     s.c1 = (unsigned)p1; s.c3 = (unsigned)p0; s.c0 = n0; s.c2 = n2;
-    s.k0 += 0x9E3779B9u; s.k1 += 0xBB67AE85u;
   }
 }
 // A kept activation that is exactly 0 is stashed as FLT_MIN: the backward pass reads "dropped" off h == 0 (no keep-bit
@@ -285,7 +292,7 @@ __device__ __forceinline__ float stash_value(float h, bool kept) {
 // sp (training only, else nullptr): this lane's slot of the group's first feature in the activation stash.
 template <bool kBits, bool kDot, int k>
 __device__ __forceinline__ void prep_micro(Prep& s, f32x4& v0, f32x4& v1, const DropDev& d, const RowCtx& c, const LayerDrop ld,
-                                           int layer, int fp, const float* wp32, float& up, bool dot_on, float* sp = nullptr) {
+                                           int layer, int fp, const float* wp32, float& up, bool dot_on, Frag3& out, float* sp = nullptr) {
   if constexpr (k == 0) {
     if (kBits) {
       const unsigned word = d.bits[((long long)c.pass * c.n_rows + c.lrow) * d.words + layer * d.nb + fp];
@@ -298,12 +305,11 @@ __device__ __forceinline__ void prep_micro(Prep& s, f32x4& v0, f32x4& v1, const 
       asm volatile("" : "+v"(kq));
       s.c0 = (unsigned)c.grow; s.c1 = (unsigned)((unsigned long long)c.grow >> 32);
       s.c2 = ((unsigned)layer << 16) | ((unsigned)fp << 2) | kq; s.c3 = d.stream + c.pass;
-      s.k0 = d.seed_lo; s.k1 = d.seed_hi;
-      philox_rounds5(s);
+      philox_rounds5<0>(s, d.seed_lo, d.seed_hi);
     }
   } else if constexpr (k == 1) {
     if (!kBits) {
-      philox_rounds5(s);
+      philox_rounds5<5>(s, d.seed_lo, d.seed_hi);
       const unsigned o[4] = {s.c0, s.c1, s.c2, s.c3};
       unsigned keep = 0;
 #pragma unroll
@@ -320,7 +326,7 @@ __device__ __forceinline__ void prep_micro(Prep& s, f32x4& v0, f32x4& v1, const 
     const float h0 = k0 ? a0 * ld.scale : 0.0f;
     const float h1 = k1 ? a1 * ld.scale : 0.0f;
     v0[r] = h0; v1[r] = h1;
-    split_pair<r>(h0, h1, s.out);
+    split_pair<r>(h0, h1, out);
     if (sp) {
       sp[r * 16] = stash_value(h0, k0);
       sp[(16 + r) * 16] = stash_value(h1, k1);
@@ -332,13 +338,14 @@ __device__ __forceinline__ void prep_micro(Prep& s, f32x4& v0, f32x4& v1, const 
   }
 }
 
-// One layer: NG K-groups, `cur` = the fragments of its group 0 on entry, of the next layer's group 0 on exit.
+// One layer: NG K-groups; st.buf[P] = the fragments of its group 0 on entry, st.buf[(P + NG) & 1] = those of the next
+// layer's group 0 on exit.  prep_in / prep_out get the buffer to fill as their last argument.
 // prep_in(g, k): micro-step k of this layer's input group g; prep_out(k): micro-step k of the NEXT layer's group 0,
 // whose raw values are this layer's acc[0], acc[1] -- final once the last slab's first tile pair is through, so
 // those steps sit in slots >= 1.  KPM / KPN: log2 row stride of this / the next matrix; NPM / NPN: (an upper bound
 // of) their 1-KB pieces per slab.
-template <int NG, int NTOUT, int KPM, int KPN, int NPM, int NPN, bool kHasOut, int WAVES = 8, typename FI, typename FO>
-__device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], Pipe6& pipe, const Mat& mine, const Mat& next, int lane, Frag3& cur, Prep& st,
+template <int P, int NG, int NTOUT, int KPM, int KPN, int NPM, int NPN, bool kHasOut, int WAVES = 8, typename FI, typename FO>
+__device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], Pipe6& pipe, const Mat& mine, const Mat& next, int lane, Prep& st,
                                          FI&& prep_in, FO&& prep_out) {
   constexpr int kSlots = NTOUT / 2, kPerDma = (48 / WAVES + kSlots - 1) / kSlots;      // <= 48 / WAVES pieces per wave and slab
   // VALU chunks: one per tile (NTOUT per slab).  The six micro-steps of the next group go to chunks
@@ -364,15 +371,14 @@ __device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], Pipe6& pipe, const
       static_for<6>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         if constexpr (kFirst + k * kAvail / 6 == c) {
-          if constexpr (g + 1 < NG) prep_in(IC<g + 1>{}, IC<k>{});
-          else if constexpr (kHasOut) prep_out(IC<k>{});
+          if constexpr (g + 1 < NG) prep_in(IC<g + 1>{}, IC<k>{}, st.buf[(P + g + 1) & 1]);
+          else if constexpr (kHasOut) prep_out(IC<k>{}, st.buf[(P + g + 1) & 1]);
         }
       });
     };
-    slab_mfma<NTOUT>(acc, cur, pipe.cur(), lane, vchunk, dma);
+    slab_mfma<NTOUT>(acc, st.buf[(P + g) & 1], pipe.cur(), lane, vchunk, dma);
     pipe.advance();
     PINN_STAMP(pipe, (NTOUT == 16 ? 0 : NTOUT == 8 ? 1 : 2));
-    cur = st.out;
   });
 }
 
@@ -411,14 +417,12 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
   const int ll = L.nh - 1;
   float up = 0.0f;
   Prep st;
-  Frag3 cur;
   f32x4 h[NT];
   layer_input_lds<NT>(h, w0t, smallp + S.b(0), xa, xb, lane);      // 8 -> H in exact fp32 (K = 8)
   {   // group 0 of the first matrix layer's input: nothing to hide it under
     const LayerDrop ld0 = layer_drop(d, c.mode, 0);
     float* sp = TRAIN ? sx->act(0, H, lane) : nullptr;
-    static_for<6>([&](auto kc) { prep_micro<kBits, true, decltype(kc)::value>(st, h[0], h[1], d, c, ld0, 0, 0, wp, up, ll == 0, sp); });
-    cur = st.out;
+    static_for<6>([&](auto kc) { prep_micro<kBits, true, decltype(kc)::value>(st, h[0], h[1], d, c, ld0, 0, 0, wp, up, ll == 0, st.buf[0], sp); });
   }
 #pragma unroll 1
   for (int l = 1; l < L.nh; ++l) {
@@ -429,14 +433,17 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
     const Mat mine{(unsigned)K.w(l), clog2(H / 16)}, next = last ? m_v0 : Mat{(unsigned)K.w(l + 1), clog2(H / 16)};
     float* sp_in = TRAIN ? sx->act(l - 1, H, lane) : nullptr;
     float* sp_out = TRAIN ? sx->act(l, H, lane) : nullptr;
-    layer_x6<NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true, WAVES>(
-        acc, pipe, mine, next, lane, cur, st,
-        [&](auto gc, auto kc) {
+    static_assert(NP % 2 == 0 && (NP / 2) % 2 == 0, "the forward layers keep the fragment buffer parity");
+    layer_x6<0, NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true, WAVES>(
+        acc, pipe, mine, next, lane, st,
+        [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value;
-          prep_micro<kBits, false, decltype(kc)::value>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, l - 1, g, wp, up, false,
+          prep_micro<kBits, false, decltype(kc)::value>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, l - 1, g, wp, up, false, out,
                                                         TRAIN ? sp_in + 32 * g * 16 : nullptr);
         },
-        [&](auto kc) { prep_micro<kBits, true, decltype(kc)::value>(st, acc[0], acc[1], d, c, ld_out, l, 0, wp, up, last, sp_out); });
+        [&](auto kc, Frag3& out) {
+          prep_micro<kBits, true, decltype(kc)::value>(st, acc[0], acc[1], d, c, ld_out, l, 0, wp, up, last, out, sp_out);
+        });
 #pragma unroll
     for (int t = 0; t < NT; ++t) h[t] = acc[t];
   }
@@ -447,14 +454,16 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
     const LayerDrop ld_in = layer_drop(d, c.mode, ll), ld_out = layer_drop(d, c.mode, L.nh);
     float* sp_in = TRAIN ? sx->act(ll, H, lane) : nullptr;
     float* sp_out = TRAIN ? tiled_ptr(sx->v1, sx->t16, H / 2, lane) : nullptr;
-    layer_x6<NP, NT2, KPW, KPV1, 3 * H / 32, 3 * H / 64, true, WAVES>(
-        v1, pipe, m_v0, m_v1, lane, cur, st,
-        [&](auto gc, auto kc) {
+    layer_x6<0, NP, NT2, KPW, KPV1, 3 * H / 32, 3 * H / 64, true, WAVES>(
+        v1, pipe, m_v0, m_v1, lane, st,
+        [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value;
-          prep_micro<kBits, true, decltype(kc)::value>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, ll, g, wp + 32 * g, up, true,
+          prep_micro<kBits, true, decltype(kc)::value>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, ll, g, wp + 32 * g, up, true, out,
                                                        TRAIN ? sp_in + 32 * g * 16 : nullptr);
         },
-        [&](auto kc) { prep_micro<kBits, false, decltype(kc)::value>(st, v1[0], v1[1], d, c, ld_out, L.nh, 0, wp, up, false, sp_out); });
+        [&](auto kc, Frag3& out) {
+          prep_micro<kBits, false, decltype(kc)::value>(st, v1[0], v1[1], d, c, ld_out, L.nh, 0, wp, up, false, out, sp_out);
+        });
   }
   u = sum_kq(up) + smallp[S.bp()];
   f32x4 v2[NT4];
@@ -462,18 +471,18 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
   {
     const LayerDrop ld_in = layer_drop(d, c.mode, L.nh);
     float* sp_in = TRAIN ? tiled_ptr(sx->v1, sx->t16, H / 2, lane) : nullptr;
-    auto prep_in = [&](auto gc, auto kc) {
+    auto prep_in = [&](auto gc, auto kc, Frag3& out) {
       constexpr int g = decltype(gc)::value;
-      prep_micro<kBits, false, decltype(kc)::value>(st, v1[2 * g], v1[2 * g + 1], d, c, ld_in, L.nh, g, wp, up, false,
+      prep_micro<kBits, false, decltype(kc)::value>(st, v1[2 * g], v1[2 * g + 1], d, c, ld_in, L.nh, g, wp, up, false, out,
                                                     TRAIN ? sp_in + 32 * g * 16 : nullptr);
     };
     if constexpr (TRAIN) {
       // the backward pass starts with Wv1^T: [H/2][H/4], row stride padded to 64
       constexpr int KPT1 = clog2((H / 4 + 63) & ~63);
       const Mat m_t1{(unsigned)K.wv1t(), clog2(H / 32)};
-      layer_x6<NP / 2, NT4, KPV1, KPT1, 3 * H / 64, 3 * H / 32, false, WAVES>(v2, pipe, m_v1, m_t1, lane, cur, st, prep_in, [&](auto) {});
+      layer_x6<0, NP / 2, NT4, KPV1, KPT1, 3 * H / 64, 3 * H / 32, false, WAVES>(v2, pipe, m_v1, m_t1, lane, st, prep_in, [&](auto, Frag3&) {});
     } else {
-      layer_x6<NP / 2, NT4, KPV1, KPW, 3 * H / 64, 3 * H / 16, false, WAVES>(v2, pipe, m_v1, first_mat<H>(K), lane, cur, st, prep_in, [&](auto) {});
+      layer_x6<0, NP / 2, NT4, KPV1, KPW, 3 * H / 64, 3 * H / 16, false, WAVES>(v2, pipe, m_v1, first_mat<H>(K), lane, st, prep_in, [&](auto, Frag3&) {});
     }
   }
   float zp = 0.0f;
@@ -514,7 +523,7 @@ struct StashRing {
 // stashed for the weight-gradient kernels (dsp) and split for the next matrix.  h = post-dropout activation from
 // the stash copy in LDS: dropped <=> h == 0, a = h / scale, d pre = d h * scale * (1 - a^2).
 template <int k>
-__device__ __forceinline__ void bprep_micro(Prep& s, f32x4& d0, f32x4& d1, const StashRing& ring, int buf, float* dsp, float scale,
+__device__ __forceinline__ void bprep_micro(Frag3& out, f32x4& d0, f32x4& d1, const StashRing& ring, int buf, float* dsp, float scale,
                                             float inv_scale) {
   if constexpr (k >= 2) {
     constexpr int r = k - 2;
@@ -525,7 +534,7 @@ __device__ __forceinline__ void bprep_micro(Prep& s, f32x4& d0, f32x4& d1, const
     d0[r] = p0; d1[r] = p1;
     dsp[r * 16] = p0;
     dsp[(16 + r) * 16] = p1;
-    split_pair<r>(p0, p1, s.out);
+    split_pair<r>(p0, p1, out);
   }
 }
 
@@ -555,7 +564,7 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
   fetch_block(0);
 
   Prep st;
-  Frag3 cur;
+  constexpr int P1 = NG1 & 1;      // fragment buffer parity after Wv1^T (its group count is odd for H = 128)
   // ---- d pre_v2 = wv2 * dz * (1 - v2^2): the B operand of Wv1^T, all in registers
   {
     float* sp = tiled_ptr(sx.dv2, sx.t16, H / 4, lane);
@@ -566,8 +575,8 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
       for (int r = 0; r < 4; ++r) v2[t][r] = w[r] * dz * (1.0f - v2[t][r] * v2[t][r]);
       store_block(sp, t, v2[t]);
     }
-    if constexpr (NT4 >= 2) cur = split3(v2[0], v2[1]);
-    else { const f32x4 zero = {0.f, 0.f, 0.f, 0.f}; cur = split3(v2[0], zero); }     // H = 128: K = 32 of a padded 64... one real block
+    if constexpr (NT4 >= 2) st.buf[0] = split3(v2[0], v2[1]);
+    else { const f32x4 zero = {0.f, 0.f, 0.f, 0.f}; st.buf[0] = split3(v2[0], zero); }     // H = 128: K = 32 of a padded 64... one real block
   }
   const Mat m_t1{(unsigned)K.wv1t(), clog2(H / 32)}, m_t0{(unsigned)K.wv0t(), clog2(H / 16)};
   const Mat m_first = first_mat<H>(K);
@@ -579,19 +588,19 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     const LayerDrop ldv = layer_drop(d, mode, nh);
     const float scale = ldv.scale, inv_scale = 1.0f / scale;
     float* dsp = tiled_ptr(sx.dv1, sx.t16, H / 2, lane);
-    layer_x6<NG1, NT2, KPT1, KPT0, 3 * H / 32, 3 * H / 16, true, WAVES>(
-        dpv1, pipe, m_t1, m_t0, lane, cur, st,
-        [&](auto gc, auto kc) {
+    layer_x6<0, NG1, NT2, KPT1, KPT0, 3 * H / 32, 3 * H / 16, true, WAVES>(
+        dpv1, pipe, m_t1, m_t0, lane, st,
+        [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
-          if constexpr (k >= 2 && 2 * g + 1 < NT4) split_pair<k - 2>(v2[2 * g][k - 2], v2[2 * g + 1][k - 2], st.out);
+          if constexpr (k >= 2 && 2 * g + 1 < NT4) split_pair<k - 2>(v2[2 * g][k - 2], v2[2 * g + 1][k - 2], out);
         },
-        [&](auto kc) {
+        [&](auto kc, Frag3& out) {
           constexpr int k = decltype(kc)::value;
           if constexpr (k == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // block 0 was requested at the top of this pass
             fetch_block(1);
           }
-          bprep_micro<k>(st, dpv1[0], dpv1[1], ring, 0, dsp, scale, inv_scale);
+          bprep_micro<k>(out, dpv1[0], dpv1[1], ring, 0, dsp, scale, inv_scale);
         });
   }
 
@@ -608,18 +617,18 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     float* dsp = tiled_ptr(sx.dv1, sx.t16, H / 2, lane);
     float* dsp_o = sx.dact(nh - 1, H, lane);
     const Mat next = nh > 1 ? Mat{(unsigned)K.wt(nh - 1), clog2(H / 16)} : m_first;
-    layer_x6<NP / 2, NT, KPT0, KPW, 3 * H / 16, 3 * H / 16, true, WAVES>(
-        dh, pipe, m_t0, next, lane, cur, st,
-        [&](auto gc, auto kc) {
+    layer_x6<P1, NP / 2, NT, KPT0, KPW, 3 * H / 16, 3 * H / 16, true, WAVES>(
+        dh, pipe, m_t0, next, lane, st,
+        [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
           if constexpr (k == 0) fetch_block(g + 1);
-          bprep_micro<k>(st, dpv1[2 * g], dpv1[2 * g + 1], ring, g & 1, dsp + 32 * g * 16, scale, inv_scale);
+          bprep_micro<k>(out, dpv1[2 * g], dpv1[2 * g + 1], ring, g & 1, dsp + 32 * g * 16, scale, inv_scale);
         },
-        [&](auto kc) {
+        [&](auto kc, Frag3& out) {
           constexpr int k = decltype(kc)::value;
           if (nh > 1) {
             if constexpr (k == 0) fetch_block(NP / 2 + 1);
-            bprep_micro<k>(st, dh[0], dh[1], ring, (NP / 2) & 1, dsp_o, scale_o, inv_scale_o);
+            bprep_micro<k>(out, dh[0], dh[1], ring, (NP / 2) & 1, dsp_o, scale_o, inv_scale_o);
           }
         });
   }
@@ -635,18 +644,18 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     float* dsp_o = sx.dact(l - 1, H, lane);
     const int base = NP / 2 + (nh - 1 - l) * NP;           // stash block index of this layer's group 0
     const Mat mine{(unsigned)K.wt(l), clog2(H / 16)}, next = l > 1 ? Mat{(unsigned)K.wt(l - 1), clog2(H / 16)} : m_first;
-    layer_x6<NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true, WAVES>(
-        acc, pipe, mine, next, lane, cur, st,
-        [&](auto gc, auto kc) {
+    layer_x6<P1, NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true, WAVES>(
+        acc, pipe, mine, next, lane, st,
+        [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
           if constexpr (k == 0) fetch_block(base + g + 1);
-          bprep_micro<k>(st, dh[2 * g], dh[2 * g + 1], ring, (base + g) & 1, dsp + 32 * g * 16, scale, inv_scale);
+          bprep_micro<k>(out, dh[2 * g], dh[2 * g + 1], ring, (base + g) & 1, dsp + 32 * g * 16, scale, inv_scale);
         },
-        [&](auto kc) {
+        [&](auto kc, Frag3& out) {
           constexpr int k = decltype(kc)::value;
           if (l > 1) {
             if constexpr (k == 0) fetch_block(base + NP + 1);
-            bprep_micro<k>(st, acc[0], acc[1], ring, (base + NP) & 1, dsp_o, scale_o, inv_scale_o);
+            bprep_micro<k>(out, acc[0], acc[1], ring, (base + NP) & 1, dsp_o, scale_o, inv_scale_o);
           }
         });
 #pragma unroll

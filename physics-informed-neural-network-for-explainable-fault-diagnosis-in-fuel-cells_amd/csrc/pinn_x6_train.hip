@@ -48,8 +48,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_chain_x6_kernel(T
     __syncthreads();
   }
   Pipe6 pipe;
-  pipe.packed = (const char*)packed; pipe.copy_bytes = (unsigned)(K.total() * 2); pipe.lds = lds_w;
-  pipe.init(threadIdx.x);
+  pipe.lds = lds_w;
+  pipe.init(packed, (unsigned)(K.total() * 2), threadIdx.x);
   pipe.prime<clog2(H), WAVES>(first_mat<H>(K));
 
   const int lane = threadIdx.x & 63, wave = pipe.wave, kq = lane >> 4;

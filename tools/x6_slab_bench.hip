@@ -12,8 +12,8 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const __bf16* packed, in
   for (int i = threadIdx.x; i < 2 * kSlabBytes / 2; i += blockDim.x) reinterpret_cast<__bf16*>(smem)[i] = (__bf16)(0.001f * (i % 977) - 0.4f);
   __syncthreads();
   Pipe6 pipe;
-  pipe.packed = (const char*)packed; pipe.copy_bytes = 1 << 20; pipe.lds = smem; pipe.par = 0;
-  pipe.init(threadIdx.x);
+  pipe.lds = smem; pipe.par = 0;
+  pipe.init(packed, 1 << 20, threadIdx.x);
   const int lane = threadIdx.x & 63;
   f32x4 acc[16];
   for (int t = 0; t < 16; ++t) acc[t] = f32x4{0, 0, 0, 0};
