@@ -498,3 +498,32 @@ def fault_labels(n_samples, data_info):
         for i in range(len(data_info["fault_data_list"])):
             lab[data_info["boundary_lines"][i]:data_info["boundary_lines"][i + 1]] = i + 1
     return lab
+
+
+# ----------------------------------------------------------------------------------------
+# Summary statistics (the numeric half of plot_model_results_detailed_split, 01:1764-1828)
+# ----------------------------------------------------------------------------------------
+def model_statistics(params, x_test_n, y_test_n, x_scal, u_scal, lam, windows=100):
+    """The 7-entry dict the reference returns (01:1819-1827), eval mode.  x_test_n / y_test_n: normalised float32
+    test rows; x_scal / u_scal: MinMaxScaler-like (min_, scale_, inverse_transform)."""
+    x = torch.as_tensor(np.asarray(x_test_n, dtype=np.float32))
+    real = torch.from_numpy(denorm(x.numpy(), *scaler_affine(x_scal)))
+    y_min, y_scale = scaler_affine(u_scal)
+    y_rescal = u_scal.inverse_transform(np.asarray(y_test_n, dtype=np.float32)).flatten()
+    u, _ = mlp_forward(params, x)
+    u = u.detach()
+    voltage_error = y_rescal - u_scal.inverse_transform(u.numpy()).flatten()
+    f_V = net_f_V(real, u, y_min, y_scale, lam)[0].detach().numpy().flatten()
+    f_T = net_f_T(real, u[:-1], y_min, y_scale, lam)[0].detach().numpy().flatten()
+    f_H = net_f_H(real, lam)[0].detach().numpy().flatten()
+    f_O = net_f_O(real, lam)[0].detach().numpy().flatten()
+    f_T_smooth = f_T if len(f_T) < windows else np.convolve(f_T, np.ones(windows) / windows, mode='same')
+    return {
+        'voltage_mae': np.mean(np.abs(voltage_error)),
+        'voltage_rmse': np.sqrt(np.mean(voltage_error ** 2)),
+        'voltage_r2': 1 - np.sum(voltage_error ** 2) / np.sum((y_rescal - np.mean(y_rescal)) ** 2),
+        'physics_v_mae': np.mean(np.abs(f_V)),
+        'temp_mae_smooth': np.mean(np.abs(f_T_smooth)),
+        'hydrogen_mae': np.mean(np.abs(f_H)),
+        'oxygen_mae': np.mean(np.abs(f_O)),
+    }

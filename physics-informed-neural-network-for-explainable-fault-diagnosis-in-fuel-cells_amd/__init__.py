@@ -2,7 +2,9 @@
 
 Public surface mirrors the reference's `01_train_pinn_multiphysics_model.py`:
 `PhysicsInformedNN`, `DNN`, `get_MC_samples`, `create_comprehensive_results_array_v2`,
-`create_fault_labels`, `smooth_by_segments`, `_moving_average_centered`.
+`create_fault_labels`, `smooth_by_segments`, `_moving_average_centered`; the steps either side of the hot path:
+`load_data_normal_raw`, `load_data_fault_raw`, `combine_and_normalize_datasets`, `add_noise_to_combined_data` (ingest),
+`plot_model_results_detailed_split` (its statistics; no figure), and `save_checkpoint` / `load_checkpoint`.
 Submodules are imported lazily so that `pinn_amd.synth` (numpy only) works without torch/HIP.
 """
 import importlib
@@ -12,7 +14,10 @@ _LAZY = {
     "get_MC_samples": "mc",
     "create_comprehensive_results_array_v2": "results", "create_fault_labels": "results",
     "smooth_by_segments": "results", "_moving_average_centered": "results",
-    "DataParallelTrainer": "dp",
+    "add_noise_to_combined_data": "ingest", "load_data_normal_raw": "ingest", "load_data_fault_raw": "ingest",
+    "combine_and_normalize_datasets": "ingest",
+    "model_statistics": "report", "plot_model_results_detailed_split": "report",
+    "save_checkpoint": "report", "load_checkpoint": "report",
 }
 
 

@@ -180,3 +180,55 @@ def test_stage_run_persistent_matches_iterated_kernels():
     b, lb = run(False)
     np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-9)
     assert abs(la - lb) <= 1e-5 * abs(lb)
+
+
+def test_model_statistics_golden():
+    """F4: the statistics dict of plot_model_results_detailed_split (01:1764-1828) from the kernels' outputs."""
+    import pinn_amd
+    from pinn_amd import synth
+    g = load_golden("g_stats.npz")
+    ds = synth.make_dataset(300, (150, 250), seed=5)
+    assert np.array_equal(ds[2].numpy(), g["x_test"])
+    m = _model_from_golden(g, ds[0].numpy(), ds[1].numpy(), ds[4], ds[5])
+    with torch.no_grad():
+        for i, v in enumerate(g["lambda_T"]):
+            getattr(m, "lambda_T%d" % (i + 1)).fill_(float(v))
+    st = pinn_amd.plot_model_results_detailed_split(m, ds, windows=100)
+    assert set(st) == {k[5:] for k in g if k.startswith("stat.")}
+    for k, v in st.items():
+        np.testing.assert_allclose(v, g["stat." + k], rtol=5e-5, err_msg=k)
+    assert not m.dnn.training
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """F4: save -> load into a fresh model reproduces parameters, physics parameters and the next dropout masks."""
+    import pinn_amd
+    from pinn_amd import synth
+    ds = synth.make_dataset(400, (), seed=2)
+
+    def fresh(seed):
+        torch.manual_seed(seed)
+        m = pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, 128, 128, 128, 1], ds[4], ds[5], p=0.2, logvar=True)
+        m.verbose = False
+        return m
+    a = fresh(1)
+    a.train_dnn(5); a.train_hydrogen(5)
+    path = os.path.join(tmp_path, "ck.pt")
+    pinn_amd.save_checkpoint(a, path)
+    ck = torch.load(path, weights_only=True)                      # tensors only
+    assert "dnn.layers.layer_0.weight" in ck and "lambda_H3" in ck
+    b = fresh(2)
+    assert not torch.equal(a.dnn._flat, b.dnn._flat)
+    pinn_amd.load_checkpoint(b, path)
+    assert torch.equal(a.dnn.flat_params(), b.dnn.flat_params()) and torch.equal(a._lambdas(), b._lambdas())
+    for k, v in a.dnn.state_dict().items():
+        assert torch.equal(v, b.dnn.state_dict()[k]), k
+    # the restored model continues exactly like the saved one (same dropout stream position)
+    a.train_dnn(3); b.train_dnn(3)
+    assert torch.equal(a.dnn.flat_params(), b.dnn.flat_params())
+    pa = pinn_amd.get_MC_samples(a, ds[2], ds[4], mc_times=4, dropout=0.4)
+    pb = pinn_amd.get_MC_samples(b, ds[2], ds[4], mc_times=4, dropout=0.4)
+    assert all(np.array_equal(x, y) for x, y in zip(pa, pb))
+    c = pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, 256, 256, 256, 1], ds[4], ds[5], p=0.2, logvar=True)
+    with pytest.raises(ValueError):
+        pinn_amd.load_checkpoint(c, path)

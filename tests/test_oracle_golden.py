@@ -175,3 +175,16 @@ def test_moving_average_is_pandas_even_window():
         a = rng.normal(size=n)
         want = pd.Series(a).rolling(window=w, center=True, min_periods=1).mean().values
         np.testing.assert_allclose(O.moving_average_centered(a, w), want, rtol=1e-12, atol=1e-14)
+
+
+def test_model_statistics_dict():
+    """01:1764-1828 on 700 synthetic test rows (thermal parameters moved off their start values)."""
+    g = load_golden("g_stats.npz")
+    sx, sy = ScalerFromArrays(g, "sx."), ScalerFromArrays(g, "sy.")
+    lam = O.init_lambdas()
+    for i, v in enumerate(g["lambda_T"]):
+        lam["lambda_T%d" % (i + 1)] = torch.tensor([v], dtype=torch.float32)
+    st = O.model_statistics(params_from_golden(g), g["x_test"], g["y_test"], sx, sy, lam, windows=100)
+    assert set(st) == {k[5:] for k in g if k.startswith("stat.")}
+    for k, v in st.items():
+        np.testing.assert_allclose(v, g["stat." + k], rtol=2e-5, err_msg=k)
