@@ -207,6 +207,20 @@ int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d_params, co
 int pinn_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, long long n,
                    float lr, int step, void* stream);
 
+/* ---- results assembly: create_comprehensive_results_array_v2 (01:1877-2010) -----------------------------------
+ * Fills d_out = float64 [n_rows, 22] row-major (the `comprehensive_results` layout scripts 02-05 read):
+ *   0-7 inputs and 8 target, de-normalised like sklearn's inverse_transform on float32 (aff->x_*, aff->y_*; 01:1916-1917);
+ *   9 = (pred_mean - mc_min) / (mc_scale + 1e-12), 10 / 11 = a_u, e_u / (mc_scale + 1e-12) (float64, 01:1925-1936),
+ *   each smoothed by a centred moving average of `window` rows with pandas' even-window semantics, separately inside
+ *   every segment [d_seg_end[k-1], d_seg_end[k]) (ascending exclusive ends, the last == n_rows; n_segments == 0: one
+ *   segment; 01:1830-1872, 01:1971-1986); 12 = col 8 - col 9; 13-16 = f_V, f_T, f_H2, f_O2; 17 = d_labels (NULL: 0);
+ *   18-21 = 5*V_est, T_pred, H2 and O2 excess ratios -- taken from d_cols as pinn_residuals(PINN_RES_ALL) wrote them.
+ * d_pred_mean / d_a_u / d_e_u: pinn_mc_dropout's outputs.  1 <= window <= 1024. */
+int pinn_results_assemble(const float* d_x, const float* d_y, const pinn_affine_t* aff, double mc_min, double mc_scale,
+                          int window, const long long* d_seg_end, int n_segments, const float* d_pred_mean,
+                          const float* d_a_u, const float* d_e_u, const float* d_cols, long long ld,
+                          const float* d_labels, long long n_rows, double* d_out, void* stream);
+
 int pinn_abi_version(void);
 
 #ifdef __cplusplus

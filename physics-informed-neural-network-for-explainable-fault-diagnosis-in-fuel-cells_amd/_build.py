@@ -16,6 +16,7 @@ ARCH = "gfx950"
 # per-file extra flags: the residual kernel mirrors torch's separately rounded float ops
 SOURCES = [
     ("pinn_residuals.hip", ["-ffp-contract=off"]),
+    ("pinn_results.hip", ["-ffp-contract=off"]),
     ("pinn_mlp.hip", []),
     ("pinn_train.hip", []),
     ("pinn_bf16.hip", []),

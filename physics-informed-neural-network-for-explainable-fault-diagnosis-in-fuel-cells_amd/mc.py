@@ -3,7 +3,7 @@ import numpy as np
 import torch
 
 
-def get_MC_samples(network, X, x_scal, mc_times=64, dropout=0.6):
+def get_MC_samples(network, X, x_scal, mc_times=64, dropout=0.6, device_outputs=False):
     """(pred_mean [N], a_u [N], e_u [N]) float32 numpy, normalised units -- same contract as 01:1413-1491.
 
     The reference runs `mc_times` identical eval passes, then `mc_times` stochastic `predict`
@@ -14,6 +14,7 @@ def get_MC_samples(network, X, x_scal, mc_times=64, dropout=0.6):
         e_u = sqrt(mean_t u_t^2 - (mean_t u_t)^2)        (01:1486: np.var, ddof=0)
     Dropout probability is overridden on ALL Dropout modules for the stochastic passes and
     restored afterwards, and the net is left in eval mode, exactly as 01:1449-1473 do.
+    device_outputs=True (not in the reference) returns the three [N] device tensors instead of numpy arrays.
     """
     original = {}
     for name, module in network.dnn.named_modules():
@@ -27,10 +28,12 @@ def get_MC_samples(network, X, x_scal, mc_times=64, dropout=0.6):
         network.dnn.train()
         row_offset = network.row_offset if X.shape[0] == network.n_local else 0
         pm, au, eu = network.mc_dropout(X, mc_times, row_offset=row_offset)
-        out = (pm.cpu().numpy(), au.cpu().numpy(), eu.cpu().numpy())
+        out = (pm, au, eu) if device_outputs else (pm.cpu().numpy(), au.cpu().numpy(), eu.cpu().numpy())
     finally:
         for name, module in network.dnn.named_modules():
             if isinstance(module, torch.nn.Dropout):
                 module.p = original[name]
         network.dnn.eval()
+    if device_outputs:
+        return out
     return tuple(np.asarray(o).squeeze() for o in out)

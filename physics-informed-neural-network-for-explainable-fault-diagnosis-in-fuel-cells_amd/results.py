@@ -1,11 +1,14 @@
 """Results assembly: the 22-column `comprehensive_results` array of 01:1877-2010.
 
-The numeric columns come from the HIP kernels (MC-dropout launch + one fused residual pass);
-de-normalisation, the per-segment centred moving average (pandas even-window semantics,
-01:1832-1834), labels and the float64 [N,22] fill are host-side numpy, as in the reference.
-`scipy.io.savemat('F01_output.mat', {'comprehensive_results': arr})` (01:2185-2186) then
-gives the file scripts 02-05 read.
+Everything per-row runs on the device: the MC-dropout launch, one fused residual pass and
+`pinn_results_assemble` (de-normalisation, the per-segment centred moving average with pandas'
+even-window semantics of 01:1832-1834, the float64 [N,22] fill); only segment ends and labels (host
+metadata) go up and the finished array comes down once.  `scipy.io.savemat('F01_output.mat',
+{'comprehensive_results': arr})` (01:2185-2186) then gives the file scripts 02-05 read.
+`_moving_average_centered` / `smooth_by_segments` are the reference's free functions (numpy, host).
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -75,60 +78,46 @@ def create_comprehensive_results_array_v2(model, dataset, mc_times=2000, dropout
     else:
         x_train, y_train, x_test, y_test, scaler_X, scaler_Y, data_info = dataset
 
-    x_test_np = x_test.detach().cpu().numpy()
-    y_test_np = y_test.detach().cpu().numpy()
-    x_test_rescaled = scaler_X.inverse_transform(x_test_np)
-    y_test_rescaled = scaler_Y.inverse_transform(y_test_np).flatten()
+    n_samples = len(x_test)
+    smooth_window = 200                                                   # 01:1972
+    # MC-dropout with the reference's dropout-rate override / restore (01:1449-1473); outputs stay on the device
+    pred_mean, a_u, e_u = get_MC_samples(model, x_test, scaler_X, mc_times=mc_times, dropout=dropout, device_outputs=True)
 
-    pred_mean_norm, ale_std_norm, epi_std_norm = get_MC_samples(model, x_test, scaler_X, mc_times=mc_times, dropout=dropout)
-
+    # min_y / scale_y as 01:1925-1930 rebuilds them from the target scaler, in float64
     lo_y, hi_y = float(scaler_Y.feature_range[0]), float(scaler_Y.feature_range[1])
-    data_min_y = np.asarray(scaler_Y.data_min_).astype(np.float64)
-    data_max_y = np.asarray(scaler_Y.data_max_).astype(np.float64)
+    data_min_y = float(np.asarray(scaler_Y.data_min_, dtype=np.float64).reshape(-1)[0])
+    data_max_y = float(np.asarray(scaler_Y.data_max_, dtype=np.float64).reshape(-1)[0])
     scale_y = (hi_y - lo_y) / (data_max_y - data_min_y + 1e-12)
     min_y = lo_y - data_min_y * scale_y
-    pred_mean_rescaled = np.asarray((pred_mean_norm - min_y) / (scale_y + 1e-12)).reshape(-1)
-    ale_std_rescaled = np.asarray(ale_std_norm / (scale_y + 1e-12)).reshape(-1)
-    epi_std_rescaled = np.asarray(epi_std_norm / (scale_y + 1e-12)).reshape(-1)
-    prediction_residual = y_test_rescaled - pred_mean_rescaled
 
     # physics residuals + physics-model outputs: one eval forward + one fused residual pass (01:1944-1969)
     model.dnn.eval()
     xd = model._dev_rows(x_test)
+    yd = y_test.detach().to(xd.device, torch.float32).reshape(-1).contiguous()
     u, _ = model.net_u(xd)
-    c = model._residuals(xd, scaler_X, _lib.RES_ALL, u=u.reshape(-1)).cpu().numpy()
-    col = lambda n: c[_lib.C[n]]
+    cols = model._residuals(xd, scaler_X, _lib.RES_ALL, u=u.reshape(-1))
 
-    smooth_window = 200
-    n_samples = len(x_test)
-    boundaries = None
+    # smoothing segments (01:1974-1986) and labels (01:2013-2047): host metadata, a few integers
+    seg_end = None
     if data_info and 'boundary_lines' in data_info and len(data_info['boundary_lines']) > 0:
-        boundaries = list(data_info['boundary_lines'])
+        boundaries = [int(b) for b in data_info['boundary_lines']]
         if boundaries[-1] != n_samples:
             boundaries = boundaries + [n_samples]
-    if boundaries:
-        ale_std_smooth = smooth_by_segments(ale_std_rescaled, boundaries, smooth_window)
-        epi_std_smooth = smooth_by_segments(epi_std_rescaled, boundaries, smooth_window)
-    else:
-        ale_std_smooth = _moving_average_centered(ale_std_rescaled, smooth_window)
-        epi_std_smooth = _moving_average_centered(epi_std_rescaled, smooth_window)
+        if not (all(0 < b <= n_samples for b in boundaries) and all(a < b for a, b in zip(boundaries[:-1], boundaries[1:]))):
+            # (the reference's slicing would leave rows of an uninitialised np.empty_like array in columns 10-11)
+            raise ValueError("data_info['boundary_lines'] must be ascending segment ends within the %d test rows" % n_samples)
+        seg_end = torch.tensor(boundaries, dtype=torch.int64, device=xd.device)
+    labels = torch.from_numpy(create_fault_labels(n_samples, data_info).astype(np.float32)).to(xd.device)
 
-    fault_labels = create_fault_labels(n_samples, data_info)
-
-    results_array = np.zeros((n_samples, 22), dtype=float)
-    results_array[:, 0:8] = x_test_rescaled
-    results_array[:, 8] = y_test_rescaled
-    results_array[:, 9] = pred_mean_rescaled
-    results_array[:, 10] = ale_std_smooth
-    results_array[:, 11] = epi_std_smooth
-    results_array[:, 12] = prediction_residual
-    results_array[:, 13] = col("FV")
-    results_array[:, 14] = col("FT")
-    results_array[:, 15] = col("FH")
-    results_array[:, 16] = col("FO")
-    results_array[:, 17] = fault_labels
-    results_array[:, 18] = col("VEST5")
-    results_array[:, 19] = col("TPRED")
-    results_array[:, 20] = col("ACTH")
-    results_array[:, 21] = col("ACTO")
-    return results_array
+    # the target scaler of THIS call may differ from the one the model was built with: its own affine map for column 8
+    aff = _lib.Affine.from_buffer_copy(model._affine(scaler_X))
+    aff.y_min = float(np.asarray(scaler_Y.min_, dtype=np.float64).reshape(-1)[0])
+    aff.y_scale = float(np.asarray(scaler_Y.scale_, dtype=np.float64).reshape(-1)[0])
+    out = torch.empty(n_samples, 22, dtype=torch.float64, device=xd.device)
+    rc = model._lib.pinn_results_assemble(
+        xd.data_ptr(), yd.data_ptr(), ctypes.byref(aff), min_y, scale_y, smooth_window,
+        None if seg_end is None else seg_end.data_ptr(), 0 if seg_end is None else int(seg_end.numel()),
+        pred_mean.data_ptr(), a_u.data_ptr(), e_u.data_ptr(), cols.data_ptr(), n_samples, labels.data_ptr(), n_samples,
+        out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pinn_results_assemble")
+    return out.cpu().numpy()
