@@ -1,6 +1,7 @@
 // Results assembly on the device: the float64 [N, 22] `comprehensive_results` array of
 // create_comprehensive_results_array_v2 (reference 01:1877-2010) in one pass over the rows.
-// HBM-bound (68 B/row read + the 20 residual columns, 176 B/row written); one workgroup = 256 consecutive rows,
+// HBM-bound (84 B/row read: rows, target, three MC outputs, eight residual columns, label; 176 B/row written);
+// one workgroup = 256 consecutive rows,
 // the smoothing windows of the two uncertainty columns staged in LDS.
 #include <hip/hip_runtime.h>
 

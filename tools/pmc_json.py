@@ -12,5 +12,7 @@ for k in sorted(acc):
         continue
     res[k] = {(c + "_KB" if c in ("FETCH_SIZE", "WRITE_SIZE") else c): acc[k][c] / cnt[k][c] for c in sorted(acc[k])}
     res[k]["launches"] = max(cnt[k].values())
+    res[k]["note"] = ("per-launch means; FETCH_SIZE_KB as rocprofv3 reports it: on gfx950 it tallies a wide coalesced streaming read "
+                      "(16 B/lane) at HALF its bytes (MI355X_MICROARCH.md, HBM) -- double it for byte counts; WRITE_SIZE_KB is exact")
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
