@@ -185,7 +185,7 @@ int pinn_mc_dropout(const pinn_net_t* net, const float* d_params, const float* d
  *   d_grads  [pinn_param_count] : SUM over local rows of d(loss_row)/dparam, already divided by
  *            n_global (so an all-reduce(SUM) over shards gives the full-batch gradient)
  *   d_loss   double[4]: sum_rows nll term, sum |logvar|, sum (y-u)^2, (spare) -- raw sums
- *   workspace from pinn_train_workspace_bytes(net, n_rows)
+ *   workspace from pinn_train_workspace_bytes(net, n_rows); d_grads and d_work 16-byte aligned (PINN_E_ARG otherwise)
  */
 size_t pinn_train_workspace_bytes(const pinn_net_t* net, long long n_rows);
 int pinn_mlp_train_grads(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y,

@@ -372,24 +372,25 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
                                                             const double* __restrict__ loss_part, int n_parts,
                                                             long long off_bp, long long off_bv2, float* __restrict__ grads,
                                                             double* __restrict__ loss_out) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // four consecutive parameters per thread (16-B loads; every tensor starts on a multiple of 4 floats, so the two scalar
+  // head biases sit at the start of a group whose other three floats are padding)
+  const long long e = 4 * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
   if (e < total) {
-    const bool pad = (e > off_bp && e < off_bp + 4) || (e > off_bv2 && e < off_bv2 + 4);
-    if (e != off_bp && e != off_bv2) {
-      float s = 0.0f;
-      if (!pad) {
-        // 16 independent loads in flight, added in slice order (fixed order -> bitwise reproducible)
-        int k = 0;
-        for (; k + 16 <= n_slices; k += 16) {
-          float v[16];
+    if (e == off_bp || e == off_bv2) {
+      grads[e + 1] = 0.0f; grads[e + 2] = 0.0f; grads[e + 3] = 0.0f;       // [e] itself: the loss-sum block below
+    } else {
+      // 8 independent 16-B loads in flight, added in slice order (fixed order -> bitwise reproducible)
+      f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+      int k = 0;
+      for (; k + 8 <= n_slices; k += 8) {
+        f32x4 v[8];
 #pragma unroll
-          for (int q = 0; q < 16; ++q) v[q] = slabs[(long long)(k + q) * total + e];
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(slabs + (long long)(k + q) * total + e);
 #pragma unroll
-          for (int q = 0; q < 16; ++q) s += v[q];
-        }
-        for (; k < n_slices; ++k) s += slabs[(long long)k * total + e];
+        for (int q = 0; q < 8; ++q) s += v[q];
       }
-      grads[e] = s;
+      for (; k < n_slices; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (long long)k * total + e);
+      *reinterpret_cast<f32x4*>(grads + e) = s;
     }
   }
   if (blockIdx.x == 0 && threadIdx.x < kLossTerms) {
@@ -505,6 +506,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
   int rc = check_net_t(net);
   if (rc) return rc;
   if (!d_params || !d_x || !d_y || !d_grads || !d_loss || !d_work || n_rows <= 0 || n_global < n_rows) return PINN_E_ARG;
+  if (((unsigned long long)d_grads | (unsigned long long)d_work) & 15) return PINN_E_ARG;      // 16-B vector accesses
   const Workspace w = plan_workspace(net, n_rows);
   if (work_bytes < w.total) return PINN_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -556,7 +558,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     b.slabs = (float*)(base + w.off_slabs); b.t16 = w.t16; b.n_slices = w.n_slices;
     if ((rc = launch_train_bf16(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, phases, &grid, stream))) return rc;
     if (phases & PINN_PHASE_REDUCE)
-      hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((L.total() + 255) / 256)), dim3(256), 0, st, b.slabs, w.n_slices,
+      hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((L.total() / 4 + 255) / 256)), dim3(256), 0, st, b.slabs, w.n_slices,
                          L.total(), a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss);
     hipError_t eb = hipGetLastError();
     return eb == hipSuccess ? PINN_OK : (int)eb;
@@ -618,7 +620,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
   }
 
   if (phases & PINN_PHASE_REDUCE)
-    hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, slabs, w.n_slices, tot,
+    hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, st, slabs, w.n_slices, tot,
                        a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;
