@@ -215,7 +215,7 @@ int pinn_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v
  *   every segment [d_seg_end[k-1], d_seg_end[k]) (ascending exclusive ends, the last == n_rows; n_segments == 0: one
  *   segment; 01:1830-1872, 01:1971-1986); 12 = col 8 - col 9; 13-16 = f_V, f_T, f_H2, f_O2; 17 = d_labels (NULL: 0);
  *   18-21 = 5*V_est, T_pred, H2 and O2 excess ratios -- taken from d_cols as pinn_residuals(PINN_RES_ALL) wrote them.
- * d_pred_mean / d_a_u / d_e_u: pinn_mc_dropout's outputs.  1 <= window <= 1024. */
+ * d_pred_mean / d_a_u / d_e_u: pinn_mc_dropout's outputs.  1 <= window <= 1024; d_x and d_out 16-byte aligned. */
 int pinn_results_assemble(const float* d_x, const float* d_y, const pinn_affine_t* aff, double mc_min, double mc_scale,
                           int window, const long long* d_seg_end, int n_segments, const float* d_pred_mean,
                           const float* d_a_u, const float* d_e_u, const float* d_cols, long long ld,
