@@ -232,3 +232,33 @@ def test_checkpoint_roundtrip(tmp_path):
     c = pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, 256, 256, 256, 1], ds[4], ds[5], p=0.2, logvar=True)
     with pytest.raises(ValueError):
         pinn_amd.load_checkpoint(c, path)
+
+
+@pytest.mark.parametrize("batch_size", [None, 256])
+def test_train_dnn_philox_masks_vs_oracle(batch_size):
+    """train_dnn with the on-chip Philox masks, full batch and minibatches (BASELINE config 4's shape in miniature): the
+    oracle replays the same masks (stream = optimizer step, row offset = first row of the batch) and takes the same Adam
+    steps; a minibatch is normalised by its own row count (01:949-955 applied per batch)."""
+    import pinn_amd
+    from pinn_amd import synth
+    N, H, epochs, seed = 600, 128, 2, 77
+    ds = synth.make_dataset(N, (), seed=9)
+    torch.manual_seed(3)
+    m = pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, H, H, H, 1], ds[4], ds[5], p=0.2, logvar=True, seed=seed)
+    m.verbose = False
+    names = O.param_names(3)
+    sd = m.dnn.state_dict()
+    P = [sd[n].detach().cpu().clone() for n in names]
+    m.train_dnn(epochs, batch_size=batch_size)
+    opt = O.AdamState(P)
+    step = 0
+    bounds = [(0, N)] if batch_size is None else [(s, min(N, s + batch_size)) for s in range(0, N, batch_size)]
+    for epoch in range(epochs):
+        for s, e in bounds:
+            step += 1
+            masks = O.philox_masks_for_net(seed, step, s, e - s, H, 3, [0.2] * 4)
+            _, _, g, _, _ = O.nll_loss_and_grads(P, ds[0][s:e], ds[1][s:e], [0.2] * 4, masks)
+            opt.step(P, g, 0.01)
+    got = m.dnn.state_dict()
+    for n, p in zip(names, P):
+        np.testing.assert_allclose(got[n].cpu().numpy(), p.detach().numpy(), rtol=5e-4, atol=5e-6, err_msg=n)
