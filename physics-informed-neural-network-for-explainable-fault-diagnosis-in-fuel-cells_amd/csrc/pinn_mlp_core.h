@@ -103,16 +103,17 @@ struct DropDev {
   int nb;                     // words per hidden-layer mask (H / 32)
 };
 
+// The round keys are wave-uniform (key + round * Weyl constant: scalar unit) and each counter update is one three-input XOR
+// (v_bitop3_b32, truth table 0x96): 20 multiplies + 20 XORs per call.
 __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
                                               unsigned k1, unsigned (&o)[4]) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
     const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
-    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    const unsigned n0 = __builtin_amdgcn_bitop3_b32((unsigned)(p1 >> 32), c1, k0 + (unsigned)r * 0x9E3779B9u, 0x96);
+    const unsigned n2 = __builtin_amdgcn_bitop3_b32((unsigned)(p0 >> 32), c3, k1 + (unsigned)r * 0xBB67AE85u, 0x96);
     c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
