@@ -88,13 +88,13 @@ def cpu_baseline(rows):
     opt = O.AdamState(P)
     gen = torch.Generator().manual_seed(0)
     times = []
-    for it in range(3):
+    for it in range(6):                                  # 1 warm-up + 5 timed repetitions, median
         t0 = time.perf_counter()
         masks = [(torch.rand(rows, w, generator=gen) >= 0.2) for w in (H, H, H, H // 2)]   # bernoulli draws, as the reference pays
         _, _, grads, _, _ = O.nll_loss_and_grads(P, x, y, [0.2] * 4, masks)
         opt.step(P, grads, 0.01)
         times.append(time.perf_counter() - t0)
-    best = min(times[1:]) if len(times) > 1 else times[0]
+    best = sorted(times[1:])[len(times[1:]) // 2]
     # stochastic forward (MC-dropout unit of work)
     t0 = time.perf_counter()
     with torch.no_grad():
@@ -102,9 +102,15 @@ def cpu_baseline(rows):
             masks = [(torch.rand(rows, w, generator=gen) >= 0.4) for w in (H, H, H, H // 2)]
             O.mlp_forward(P, x, [0.4] * 4, masks)
     fwd = (time.perf_counter() - t0) / 2
+    model_name = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model_name = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
     return {"value": rows / best, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "train_dnn step (fwd+NLL+autograd bwd+Adam, torch-bernoulli masks) of oracle/pinn_oracle.py on %d rows, "
-                      "best of 2 after 1 warm-up; os.cpu_count()=%d" % (rows, os.cpu_count()),
+                      "median of 5 after 1 warm-up; os.cpu_count()=%d; %s" % (rows, os.cpu_count(), model_name),
             "mc_fwd_passes_per_s": rows / fwd}
 
 

@@ -262,3 +262,22 @@ def test_train_dnn_philox_masks_vs_oracle(batch_size):
     got = m.dnn.state_dict()
     for n, p in zip(names, P):
         np.testing.assert_allclose(got[n].cpu().numpy(), p.detach().numpy(), rtol=5e-4, atol=5e-6, err_msg=n)
+
+
+def test_reference_main_flow(tmp_path):
+    """The reference's `__main__` (01:2055-2201) end to end on synthetic recordings: ingest -> seven trainer calls -> results
+    array -> .mat as scripts 02-05 read it (02:105-114), at 0.2 % of the schedule."""
+    import importlib.util
+    import scipy.io
+    spec = importlib.util.spec_from_file_location("reference_main", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples",
+                                                                                  "reference_main.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = os.path.join(tmp_path, "F01_output.mat")
+    arr, _ = mod.main(["--scale", "0.002", "--out", out, "--quiet"])
+    assert arr.shape == (3000 + 3 * 400, 22) and np.all(np.isfinite(arr))
+    back = scipy.io.loadmat(out)["comprehensive_results"]
+    assert np.array_equal(back, arr)
+    assert set(np.unique(arr[:, 17])) == {0.0, 1.0, 2.0, 3.0}
+    assert np.all(arr[:3000, 17] == 0) and np.all(arr[3000:3400, 17] == 1)
+    np.testing.assert_allclose(arr[:, 12], arr[:, 8] - arr[:, 9], rtol=0, atol=1e-12)
