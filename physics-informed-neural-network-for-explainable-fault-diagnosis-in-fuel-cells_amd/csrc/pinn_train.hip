@@ -286,12 +286,30 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
   long long t_end = t_begin + per;
   if (t_end > a.t16) t_end = a.t16;
 
-  // software pipeline: the fragments of tile t+1 are in flight while tile t multiplies
-  WFrag<TI, TJ> cur, nxt;
-  if (t_begin < t_end) wgrad_load<TI, TJ, QX>(cur, a, t_begin, i0, j0, hh, i);
-  for (long long t = t_begin; t < t_end; ++t) {
-    const long long tn = (t + 1 < t_end) ? t + 1 : t;
-    wgrad_load<TI, TJ, QX>(nxt, a, tn, i0, j0, hh, i);
+  // software pipeline, two tiles deep where the registers allow (< 256 accumulator registers): the fragments and the
+  // vector-head operands of tiles t+1 and t+2 are in flight while tile t multiplies (one tile ahead is about one HBM
+  // latency of work; the layer-0 kernel streamed at 2.9 TB/s with it)
+  constexpr bool kDeep = TI * TJ < 16;
+  struct Side { f32x4 r[kDeep ? TI : 1][2], s2[2], s1[2]; };      // operands of the vector-head sums (prefetched iff kDeep)
+  const bool want_r = wj == 0 && a.dvr, want_q = wi == 0 && a.dvq;
+  auto load_r = [&](long long t, int ti, int sg) { return *reinterpret_cast<const f32x4*>(a.R + ((t * a.OUT + i0 + i) * 16 + 8 * hh) + ti * 512 + sg * 4); };
+  auto load_s = [&](const float* sv, long long t, int sg) { return *reinterpret_cast<const f32x4*>(sv + t * 16 + 8 * hh + sg * 4); };
+  auto fetch = [&](WFrag<TI, TJ>& f, Side& sd, long long t) {
+    if (t >= t_end) t = t_end - 1;
+    wgrad_load<TI, TJ, QX>(f, a, t, i0, j0, hh, i);
+    if constexpr (kDeep) {
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg) {
+        if (want_r) {
+          sd.s2[sg] = load_s(a.s2, t, sg);
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti) sd.r[ti][sg] = load_r(t, ti, sg);
+        }
+        if (want_q) sd.s1[sg] = load_s(a.s1, t, sg);
+      }
+    }
+  };
+  auto tile = [&](const WFrag<TI, TJ>& cur, const Side& sd, long long t) {
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg)
 #pragma unroll
@@ -306,30 +324,49 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) bsum[ti] += (cur.a[ti][sg][0] + cur.a[ti][sg][1]) + (cur.a[ti][sg][2] + cur.a[ti][sg][3]);
       if (a.dvr) {
-        const float* pR = a.R + ((t * a.OUT + i0 + i) * 16 + 8 * hh);
-        const float* ps = a.s2 + t * 16 + 8 * hh;
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
-          const f32x4 sv = *reinterpret_cast<const f32x4*>(ps + sg * 4);
+          f32x4 sv;
+          if constexpr (kDeep) sv = sd.s2[sg]; else sv = load_s(a.s2, t, sg);
 #pragma unroll
           for (int ti = 0; ti < TI; ++ti) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(pR + ti * 512 + sg * 4);
+            f32x4 rv;
+            if constexpr (kDeep) rv = sd.r[ti][sg]; else rv = load_r(t, ti, sg);
             vr[ti] += (sv[0] * rv[0] + sv[1] * rv[1]) + (sv[2] * rv[2] + sv[3] * rv[3]);
           }
         }
       }
     }
     if (wi == 0 && a.dvq) {
-      const float* ps = a.s1 + t * 16 + 8 * hh;
 #pragma unroll
       for (int sg = 0; sg < 2; ++sg) {
-        const f32x4 sv = *reinterpret_cast<const f32x4*>(ps + sg * 4);
+        f32x4 sv;
+        if constexpr (kDeep) sv = sd.s1[sg]; else sv = load_s(a.s1, t, sg);
 #pragma unroll
         for (int tj = 0; tj < TJ; ++tj)
           vq[tj] += (sv[0] * cur.b[tj][sg][0] + sv[1] * cur.b[tj][sg][1]) + (sv[2] * cur.b[tj][sg][2] + sv[3] * cur.b[tj][sg][3]);
       }
     }
-    cur = nxt;
+  };
+  if constexpr (kDeep) {
+    WFrag<TI, TJ> f0, f1, f2;
+    Side d0, d1, d2;
+    if (t_begin < t_end) { fetch(f0, d0, t_begin); fetch(f1, d1, t_begin + 1); }
+    for (long long t = t_begin; t < t_end; t += 3) {
+      fetch(f2, d2, t + 2);
+      tile(f0, d0, t);
+      if (t + 1 < t_end) { fetch(f0, d0, t + 3); tile(f1, d1, t + 1); }
+      if (t + 2 < t_end) { fetch(f1, d1, t + 4); tile(f2, d2, t + 2); }
+    }
+  } else {
+    WFrag<TI, TJ> cur, nxt;
+    Side none;
+    if (t_begin < t_end) fetch(cur, none, t_begin);
+    for (long long t = t_begin; t < t_end; ++t) {
+      fetch(nxt, none, t + 1);
+      tile(cur, none, t);
+      cur = nxt;
+    }
   }
 
   // ---- write this slice's slab
