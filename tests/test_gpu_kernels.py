@@ -197,3 +197,38 @@ def test_residuals_partial_flags_and_determinism(lib):
     for fn, key in ((O.net_f_T_simple, "FT2"), (O.net_f_H, "FH2"), (O.net_f_O, "FO2")):
         want = float((fn(real, lamo)[0].double() ** 2).sum())
         assert abs(outs[0][_lib.S[key]] - want) <= 1e-5 * abs(want)
+
+
+@pytest.mark.parametrize("N", [1, 257, 100003, 1000000])
+def test_residuals_cached_matches_residuals(lib, N):
+    """pinn_residuals_prepare + pinn_residuals_cached (row cache of the parameter-independent half) give the sums of
+    pinn_residuals for every stage, at the initial parameters and after moving them (the cache must not depend on them)."""
+    import hip_helpers as hh
+    from pinn_amd import _lib, synth
+    ds = synth.make_dataset(N, (), seed=6)
+    aff = hh.affine_struct(ds[4], ds[5])
+    x, y = ds[0].to(hh.dev()), ds[1].reshape(-1).to(hh.dev())
+    u = (y + 0.05 * torch.randn(N, device=hh.dev())).contiguous()
+    lam0 = torch.tensor([O.LAMBDA_INIT[n] for n in O.LAMBDA_NAMES], dtype=torch.float32)
+    lam1 = lam0 * torch.tensor([1.3, 0.8, 1.7, 1.0, 0.5, 1.0, 2.0, 1.0, 0.3, 1.4, 0.9, 0.7, 1.0, 1.2, 3.0, 0.6, 1.0])
+    wb = lib.pinn_residuals_workspace_bytes()
+    work = torch.empty(wb, dtype=torch.uint8, device=hh.dev())
+    cache = torch.empty(6 * N, dtype=torch.float32, device=hh.dev())
+    for flags in (_lib.RES_V, _lib.RES_T, _lib.RES_H, _lib.RES_O):
+        _lib.check(lib.pinn_residuals_prepare(hh.ptr(x), hh.ptr(u), hh.ptr(y), ctypes.byref(aff), hh.ptr(lam0.to(hh.dev())), flags, N,
+                                              hh.ptr(cache), hh.stream()), "prepare")
+        for lam in (lam0, lam1):
+            ld = lam.to(hh.dev())
+            a = torch.zeros(_lib.NSUMS, dtype=torch.float64, device=hh.dev())
+            b = torch.full((_lib.NSUMS,), 7.0, dtype=torch.float64, device=hh.dev())
+            _lib.check(lib.pinn_residuals(hh.ptr(x), hh.ptr(u), hh.ptr(y), ctypes.byref(aff), hh.ptr(ld), flags, N, None, 0, hh.ptr(a),
+                                          hh.ptr(work), wb, hh.stream()), "residuals")
+            _lib.check(lib.pinn_residuals_cached(hh.ptr(cache), ctypes.byref(aff), hh.ptr(ld), flags, N, hh.ptr(b), hh.ptr(work), wb,
+                                                 hh.stream()), "cached")
+            a, b = a.cpu().numpy(), b.cpu().numpy()
+            assert np.all(np.isfinite(b))
+            np.testing.assert_allclose(b, a, rtol=2e-6, atol=1e-6 * max(1.0, np.abs(a).max()) * 1e-3, err_msg="flags %d" % flags)
+            assert np.array_equal(b == 0.0, a == 0.0)
+    sums = torch.zeros(_lib.NSUMS, dtype=torch.float64, device=hh.dev())
+    assert lib.pinn_residuals_cached(hh.ptr(cache), ctypes.byref(aff), hh.ptr(lam0.to(hh.dev())), _lib.RES_ALL, N, hh.ptr(sums), hh.ptr(work), wb,
+                                     hh.stream()) == -1                   # exactly one stage per cache

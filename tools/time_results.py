@@ -34,8 +34,25 @@ for N in (int(a) for a in (sys.argv[1:] or ["1000000", "10000000"])):
         _lib.check(lib.pinn_residuals(hh.ptr(x), hh.ptr(y), hh.ptr(y), ctypes.byref(aff), hh.ptr(lam), _lib.RES_ALL, N, None, 0, hh.ptr(sums),
                                       hh.ptr(work), work.numel(), hh.stream()), "residuals")
 
-    for name, fn, bytes_row in (("results_assemble", assemble, 84 + 176), ("residuals (all, 20 columns out)", resid_cols, 40 + 80),
-                                ("residuals (all, sums only)", resid_sums, 40)):
+    cache = torch.empty(6 * N, dtype=torch.float32, device=dev)
+
+    def stage(flags, cached):
+        def run():
+            if cached:
+                _lib.check(lib.pinn_residuals_cached(hh.ptr(cache), ctypes.byref(aff), hh.ptr(lam), flags, N, hh.ptr(sums), hh.ptr(work),
+                                                     work.numel(), hh.stream()), "cached")
+            else:
+                _lib.check(lib.pinn_residuals(hh.ptr(x), hh.ptr(y), hh.ptr(y), ctypes.byref(aff), hh.ptr(lam), flags, N, None, 0, hh.ptr(sums),
+                                              hh.ptr(work), work.numel(), hh.stream()), "residuals")
+        return run
+
+    cases = [("results_assemble", assemble, 84 + 176), ("residuals (all, 20 columns out)", resid_cols, 40 + 80),
+             ("residuals (all, sums only)", resid_sums, 40)]
+    for tag, flags, nc in (("V", _lib.RES_V, 6), ("T", _lib.RES_T, 4), ("H", _lib.RES_H, 2), ("O", _lib.RES_O, 2)):
+        cases.append(("stage %s sums, from the rows" % tag, stage(flags, False), 40))
+        _lib.check(lib.pinn_residuals_prepare(hh.ptr(x), hh.ptr(y), hh.ptr(y), ctypes.byref(aff), hh.ptr(lam), flags, N, hh.ptr(cache), hh.stream()), "prep")
+        cases.append(("stage %s sums, from the row cache" % tag, stage(flags, True), 4 * nc))
+    for name, fn, bytes_row in cases:
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
