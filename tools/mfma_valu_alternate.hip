@@ -1,13 +1,17 @@
 // How much of a VALU chunk hides under the other wave's MFMA group?  Two waves per SIMD (one 512-thread workgroup per CU),
 // each alternating G bf16 MFMAs (one dependent chain) with K VALU ops -- the x6 chain's shape -- with / without a barrier
-// every 16 groups, with AGPR accumulators, two interleaved chains, the second wave of a SIMD running its chunk BEFORE its
-// MFMAs, or pure roles (waves 0-3 only MFMAs, 4-7 only VALU).  Measured law (-DVMODE=0..5 = shift-add / xor-add / Philox-like
-// multiply / exp+rcp / independent xor / dependent xor-add streams): t(both) ~= t(MFMA) + t(VALU) - c * min(...), c = 0.25-0.6,
-// whatever the granularity, chain structure, accumulator file or barrier; staggering and pure roles inside one workgroup
-// are worse.  (tools/mfma_valu_share.hip: an MFMA-only and a VALU-only WORKGROUP per CU do overlap ~100 %.)
+// every 16 groups, with AGPR accumulators, two interleaved chains, or the second wave of a SIMD running its chunk BEFORE its
+// MFMAs.  Measured law (-DVMODE=0..5 = shift-add / xor-add / Philox-like multiply / exp+rcp / independent xor / dependent
+// xor-add streams): t(both) ~= t(MFMA) + t(VALU) - c * min(...), c = 0.25-0.6, whatever the granularity, chain structure,
+// accumulator file or barrier; the staggered variant is worse.  (The "roles" variant -- waves 0-3 only MFMAs, 4-7 only VALU,
+// one of each per SIMD since wave w runs on SIMD w % 4 -- measures slower than the SUM of its parts and is not understood;
+// tools/mfma_valu_share.hip, an MFMA-only and a VALU-only WORKGROUP per CU, overlaps ~100 %.)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DVMODE=1 -o mfma_valu_alternate tools/mfma_valu_alternate.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#ifndef ROLE_ODD
+#define ROLE_ODD 0
+#endif
 #ifndef VMODE
 #define VMODE 0
 #endif
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int iters) {
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-      if (ROLE) { if (wave >= 4) { valu(); __builtin_amdgcn_sched_barrier(0); valu(); } else { mfma(t); __builtin_amdgcn_sched_barrier(0); mfma(t + 1); } }
+      if (ROLE) { if (ROLE_ODD ? (wave & 1) : (wave >= 4)) { valu(); __builtin_amdgcn_sched_barrier(0); valu(); } else { mfma(t); __builtin_amdgcn_sched_barrier(0); mfma(t + 1); } }
       else if (STAGGER && wave >= 4) { valu(); __builtin_amdgcn_sched_barrier(0); mfma(t); }
       else { mfma(t); __builtin_amdgcn_sched_barrier(0); valu(); }
       __builtin_amdgcn_sched_barrier(0);
