@@ -93,7 +93,7 @@ __device__ __forceinline__ void load_small_params(float* __restrict__ sp, const 
 // ---------------------------------------------------------------------------------------
 struct DropDev {
   int mode;
-  unsigned thr[kMaxDrop];     // 16-bit drop thresholds: keep iff draw16 >= thr
+  unsigned thr[kMaxDrop];     // 8-bit drop thresholds round(256 p): keep iff draw8 >= thr
   float scale[kMaxDrop];      // 1 / (1 - p) in float32 (torch: noise.div_(1 - p))
   unsigned seed_lo, seed_hi;
   unsigned stream;
@@ -130,9 +130,10 @@ struct RowCtx {
 
 // 8 keep bits of the 32-feature group `fp` (= two 16-feature blocks 2fp, 2fp+1) of dropout
 // module `layer` for this lane's row: bit 4*b + r <-> register r of block 2fp + b, i.e. feature
-// 32fp + 16b + 4kq + r.  ONE Philox call = eight 16-bit draws = exactly this lane's share:
-//     counter = (global_row lo, hi, layer << 16 | fp << 2 | kq, stream + pass), key = seed
-//     draw index 4b + r -> word (4b + r) >> 1, half (4b + r) & 1.
+// 32fp + 16b + 4kq + r.  ONE Philox call = sixteen 8-bit draws = this lane's share of the PAIR of
+// 32-groups (fp & ~1, fp | 1):
+//     counter = (global_row lo, hi, layer << 16 | (fp >> 1) << 2 | kq, stream + pass), key = seed
+//     draw index 8 (fp & 1) + 4b + r -> word (index >> 2), byte (index & 3); keep iff byte >= thr.
 // Branch-free: eval mode is thr = 0 (every draw kept).  kBits (parity-test kernels only) reads
 // injected bit masks instead.
 template <bool kBits>
@@ -144,12 +145,13 @@ __device__ __forceinline__ unsigned keep_bits8(const DropDev& d, const RowCtx& c
   }
   unsigned o[4];
   philox4x32_10((unsigned)c.grow, (unsigned)((unsigned long long)c.grow >> 32),
-                ((unsigned)layer << 16) | ((unsigned)fp << 2) | (unsigned)c.kq, d.stream + c.pass, d.seed_lo, d.seed_hi, o);
+                ((unsigned)layer << 16) | ((unsigned)(fp >> 1) << 2) | (unsigned)c.kq, d.stream + c.pass, d.seed_lo, d.seed_hi, o);
+  const unsigned wa = (fp & 1) ? o[2] : o[0], wb = (fp & 1) ? o[3] : o[1];
   unsigned keep = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    keep |= ((o[w] & 0xFFFFu) >= thr ? 1u : 0u) << (2 * w);
-    keep |= ((o[w] >> 16) >= thr ? 1u : 0u) << (2 * w + 1);
+  for (int r = 0; r < 4; ++r) {
+    keep |= (((wa >> (8 * r)) & 0xFFu) >= thr ? 1u : 0u) << r;
+    keep |= (((wb >> (8 * r)) & 0xFFu) >= thr ? 1u : 0u) << (4 + r);
   }
   return keep;
 }

@@ -566,8 +566,8 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
         for (int l = 0; l <= nh; ++l) {
           const float p = drop->p[l];
           if (!(p >= 0.0f && p < 1.0f)) return PINN_E_ARG;
-          double t = floor((double)p * 65536.0 + 0.5);
-          d.thr[l] = (unsigned)(t < 0 ? 0 : (t > 65536.0 ? 65536.0 : t));
+          double t = floor((double)p * 256.0 + 0.5);
+          d.thr[l] = (unsigned)(t < 0 ? 0 : (t > 256.0 ? 256.0 : t));
           d.scale[l] = 1.0f / (float)(1.0 - (double)p);
         }
         d.seed_lo = (unsigned)(drop->seed & 0xFFFFFFFFull); d.seed_hi = (unsigned)(drop->seed >> 32); d.stream = drop->stream;

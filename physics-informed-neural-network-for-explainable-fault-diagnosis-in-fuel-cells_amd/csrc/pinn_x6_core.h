@@ -262,12 +262,12 @@ __device__ __forceinline__ void layer_input_lds(f32x4 (&acc)[NTOUT], const float
 
 // ---------------------------------------------------------------------------------------
 // preparing a 32-feature K-group (two 16-feature blocks v0, v1 of raw pre-activations -> activated in
-// place -> Frag3) in six micro-steps: 0, 1 = Philox4x32-10 (five rounds each) and the 8 keep bits;
+// place -> Frag3) in six micro-steps: 0, 1 = Philox4x32-10 (five rounds each; even groups only: one call = 16 draws);
 // 2 .. 5 = register r = k - 2 of both blocks: tanh, dropout, 3-way split (and the predict head's dot).
 // ---------------------------------------------------------------------------------------
 struct Prep {
-  unsigned c0, c1, c2, c3;   // Philox counter between micro-steps 0 and 1
-  unsigned keep;
+  unsigned w0, w1, w2, w3;   // Philox counter / output words: one call = sixteen 8-bit draws = a lane's share of TWO 32-groups
+  unsigned keep;             // injected masks (kBits) only
   Frag3 buf[2];      // fragments of the group in the MFMAs / of the group being prepared, alternating (static parity)
 };
 // Rounds R0 .. R0 + 4.  The round keys are wave-uniform (seed + round * Weyl constant): they stay on the scalar unit,
@@ -276,12 +276,18 @@ template <int R0>
 __device__ __forceinline__ void philox_rounds5(Prep& s, unsigned seed_lo, unsigned seed_hi) {
 #pragma unroll
   for (int r = R0; r < R0 + 5; ++r) {
-    const unsigned long long p0 = (unsigned long long)0xD2511F53u * s.c0;
-    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * s.c2;
-    const unsigned n0 = __builtin_amdgcn_bitop3_b32((unsigned)(p1 >> 32), s.c1, seed_lo + (unsigned)r * 0x9E3779B9u, 0x96);
-    const unsigned n2 = __builtin_amdgcn_bitop3_b32((unsigned)(p0 >> 32), s.c3, seed_hi + (unsigned)r * 0xBB67AE85u, 0x96);
-    s.c1 = (unsigned)p1; s.c3 = (unsigned)p0; s.c0 = n0; s.c2 = n2;
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * s.w0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * s.w2;
+    const unsigned n0 = __builtin_amdgcn_bitop3_b32((unsigned)(p1 >> 32), s.w1, seed_lo + (unsigned)r * 0x9E3779B9u, 0x96);
+    const unsigned n2 = __builtin_amdgcn_bitop3_b32((unsigned)(p0 >> 32), s.w3, seed_hi + (unsigned)r * 0xBB67AE85u, 0x96);
+    s.w1 = (unsigned)p1; s.w3 = (unsigned)p0; s.w0 = n0; s.w2 = n2;
   }
+}
+// draw of register r of block b of the 32-group with parity par inside its 64-feature pair: byte r of word 2 par + b
+template <int PAR, int B, int R>
+__device__ __forceinline__ bool keep_draw(const Prep& s, unsigned thr) {
+  const unsigned w = PAR == 0 ? (B == 0 ? s.w0 : s.w1) : (B == 0 ? s.w2 : s.w3);
+  return ((w >> (8 * R)) & 0xFFu) >= thr;
 }
 // A kept activation that is exactly 0 is stashed as FLT_MIN: the backward pass reads "dropped" off h == 0 (no keep-bit
 // stash), and FLT_MIN contributes nothing anywhere (1 - a^2 == 1, products with it underflow).
@@ -290,39 +296,32 @@ __device__ __forceinline__ float stash_value(float h, bool kept) {
 }
 // wp32: the predict head's 32 weights of this group (LDS) when kDot; the dot is accumulated only if dot_on.
 // sp (training only, else nullptr): this lane's slot of the group's first feature in the activation stash.
-template <bool kBits, bool kDot, int k>
+// FP: the 32-group's index inside its dropout layer; the even group of a pair runs the Philox call, both read it.
+template <bool kBits, bool kDot, int k, int FP>
 __device__ __forceinline__ void prep_micro(Prep& s, f32x4& v0, f32x4& v1, const DropDev& d, const RowCtx& c, const LayerDrop ld,
-                                           int layer, int fp, const float* wp32, float& up, bool dot_on, Frag3& out, float* sp = nullptr) {
+                                           int layer, const float* wp32, float& up, bool dot_on, Frag3& out, float* sp = nullptr) {
+  constexpr int fp = FP, par = FP & 1;
   if constexpr (k == 0) {
     if (kBits) {
       const unsigned word = d.bits[((long long)c.pass * c.n_rows + c.lrow) * d.words + layer * d.nb + fp];
       const unsigned lo = (word >> (4 * c.kq)) & 0xFu, hi = (word >> (16 + 4 * c.kq)) & 0xFu;
       s.keep = ld.thr == 0 ? 0xFFu : (lo | (hi << 4));
-    } else {
+    } else if constexpr (par == 0) {
       // the counter passes through an empty volatile asm: otherwise hipcc computes every group's first rounds once,
       // outside the pass loop, and keeps them in registers (spills)
       unsigned kq = (unsigned)c.kq;
       asm volatile("" : "+v"(kq));
-      s.c0 = (unsigned)c.grow; s.c1 = (unsigned)((unsigned long long)c.grow >> 32);
-      s.c2 = ((unsigned)layer << 16) | ((unsigned)fp << 2) | kq; s.c3 = d.stream + c.pass;
+      s.w0 = (unsigned)c.grow; s.w1 = (unsigned)((unsigned long long)c.grow >> 32);
+      s.w2 = ((unsigned)layer << 16) | ((unsigned)(fp >> 1) << 2) | kq; s.w3 = d.stream + c.pass;
       philox_rounds5<0>(s, d.seed_lo, d.seed_hi);
     }
   } else if constexpr (k == 1) {
-    if (!kBits) {
-      philox_rounds5<5>(s, d.seed_lo, d.seed_hi);
-      const unsigned o[4] = {s.c0, s.c1, s.c2, s.c3};
-      unsigned keep = 0;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        keep |= ((o[w] & 0xFFFFu) >= ld.thr ? 1u : 0u) << (2 * w);
-        keep |= ((o[w] >> 16) >= ld.thr ? 1u : 0u) << (2 * w + 1);
-      }
-      s.keep = keep;
-    }
+    if constexpr (!kBits && par == 0) philox_rounds5<5>(s, d.seed_lo, d.seed_hi);
   } else {
     constexpr int r = k - 2;
     const float a0 = tanh_f32(v0[r]), a1 = tanh_f32(v1[r]);
-    const bool k0 = (s.keep >> r) & 1u, k1 = (s.keep >> (4 + r)) & 1u;
+    const bool k0 = kBits ? ((s.keep >> r) & 1u) != 0 : keep_draw<par, 0, r>(s, ld.thr);
+    const bool k1 = kBits ? ((s.keep >> (4 + r)) & 1u) != 0 : keep_draw<par, 1, r>(s, ld.thr);
     const float h0 = k0 ? a0 * ld.scale : 0.0f;
     const float h1 = k1 ? a1 * ld.scale : 0.0f;
     v0[r] = h0; v1[r] = h1;
@@ -422,7 +421,7 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
   {   // group 0 of the first matrix layer's input: nothing to hide it under
     const LayerDrop ld0 = layer_drop(d, c.mode, 0);
     float* sp = TRAIN ? sx->act(0, H, lane) : nullptr;
-    static_for<6>([&](auto kc) { prep_micro<kBits, true, decltype(kc)::value>(st, h[0], h[1], d, c, ld0, 0, 0, wp, up, ll == 0, st.buf[0], sp); });
+    static_for<6>([&](auto kc) { prep_micro<kBits, true, decltype(kc)::value, 0>(st, h[0], h[1], d, c, ld0, 0, wp, up, ll == 0, st.buf[0], sp); });
   }
 #pragma unroll 1
   for (int l = 1; l < L.nh; ++l) {
@@ -438,11 +437,11 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
         acc, pipe, mine, next, lane, st,
         [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value;
-          prep_micro<kBits, false, decltype(kc)::value>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, l - 1, g, wp, up, false, out,
+          prep_micro<kBits, false, decltype(kc)::value, g>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, l - 1, wp, up, false, out,
                                                         TRAIN ? sp_in + 32 * g * 16 : nullptr);
         },
         [&](auto kc, Frag3& out) {
-          prep_micro<kBits, true, decltype(kc)::value>(st, acc[0], acc[1], d, c, ld_out, l, 0, wp, up, last, out, sp_out);
+          prep_micro<kBits, true, decltype(kc)::value, 0>(st, acc[0], acc[1], d, c, ld_out, l, wp, up, last, out, sp_out);
         });
 #pragma unroll
     for (int t = 0; t < NT; ++t) h[t] = acc[t];
@@ -458,11 +457,11 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
         v1, pipe, m_v0, m_v1, lane, st,
         [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value;
-          prep_micro<kBits, true, decltype(kc)::value>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, ll, g, wp + 32 * g, up, true, out,
+          prep_micro<kBits, true, decltype(kc)::value, g>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, ll, wp + 32 * g, up, true, out,
                                                        TRAIN ? sp_in + 32 * g * 16 : nullptr);
         },
         [&](auto kc, Frag3& out) {
-          prep_micro<kBits, false, decltype(kc)::value>(st, v1[0], v1[1], d, c, ld_out, L.nh, 0, wp, up, false, out, sp_out);
+          prep_micro<kBits, false, decltype(kc)::value, 0>(st, v1[0], v1[1], d, c, ld_out, L.nh, wp, up, false, out, sp_out);
         });
   }
   u = sum_kq(up) + smallp[S.bp()];
@@ -473,7 +472,7 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
     float* sp_in = TRAIN ? tiled_ptr(sx->v1, sx->t16, H / 2, lane) : nullptr;
     auto prep_in = [&](auto gc, auto kc, Frag3& out) {
       constexpr int g = decltype(gc)::value;
-      prep_micro<kBits, false, decltype(kc)::value>(st, v1[2 * g], v1[2 * g + 1], d, c, ld_in, L.nh, g, wp, up, false, out,
+      prep_micro<kBits, false, decltype(kc)::value, g>(st, v1[2 * g], v1[2 * g + 1], d, c, ld_in, L.nh, wp, up, false, out,
                                                     TRAIN ? sp_in + 32 * g * 16 : nullptr);
     };
     if constexpr (TRAIN) {

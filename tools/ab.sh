@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B timing of library variants on one box: tools/ab.sh OUTFILE lib1.so lib2.so ...  ("main" = the in-tree library)
+out=$1; shift
+mkdir -p "$(dirname "$out")"
+: > "$out"
+for rep in 1 2; do
+  for lib in "$@"; do
+    if [ "$lib" = main ]; then unset PINN_HIP_LIB; else export PINN_HIP_LIB=$lib; fi
+    echo "== $lib (rep $rep)" >> "$out"
+    timeout -k 10 300 python tools/time_forward.py 2 >> "$out" 2>&1 || exit 1
+    timeout -k 10 300 python tools/time_train.py 2 >> "$out" 2>&1 || exit 1
+  done
+done
