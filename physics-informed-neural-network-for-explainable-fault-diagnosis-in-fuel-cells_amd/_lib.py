@@ -101,10 +101,13 @@ def load(build_if_missing=True):
         path, build_if_missing = override, False
     if build_if_missing:
         try:
-            path = _build.build()
-        except RuntimeError:
-            if not os.path.exists(path):
-                raise
+            path = _build.build()          # no-op when the library matches the sources (content hashes)
+        except _build.NoCompiler:
+            # a box without hipcc may only run a library that was built from exactly these sources;
+            # a compile or link FAILURE (BuildError) always propagates: never run a stale binary
+            if not _build.is_current():
+                raise PinnError("libpinn_hip.so is missing or does not match the sources in %s, and hipcc is not "
+                                "available to rebuild it" % _build.CSRC)
     if not os.path.exists(path):
         raise PinnError("libpinn_hip.so is missing (%s): build it with __graft_entry__.build()" % path)
     lib = ctypes.CDLL(path)

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp_x6_kernel(FwdArgs a
   pipe.init(packed, (unsigned)(K.total() * 2), threadIdx.x);
   pipe.prime<clog2(H), WAVES>(first_mat<H>(K));
 #ifdef PINN_X6_STAMP
-  for (int k = 0; k < 4; ++k) pipe.seg[k] = 0;
+  for (int k = 0; k < 8; ++k) pipe.seg[k] = 0;
   pipe.last = stamp();
 #endif
 
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp_x6_kernel(FwdArgs a
   }
 #ifdef PINN_X6_STAMP
   if (blockIdx.x == 0 && lane == 0)
-    for (int k = 0; k < 4; ++k) g_x6_stamps[wave * 4 + k] = pipe.seg[k];
+    for (int k = 0; k < 8; ++k) g_x6_stamps[wave * 8 + k] = pipe.seg[k];
 #endif
 }
 
@@ -189,6 +189,6 @@ int launch_forward_x6(const pinn_net_t* net, const FwdArgs& a, bool mc, void* st
 
 #ifdef PINN_X6_STAMP
 extern "C" int pinn_x6_debug_read(unsigned long long* host) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pinn::x6::g_x6_stamps), sizeof(unsigned long long) * 32);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pinn::x6::g_x6_stamps), sizeof(unsigned long long) * 64);
 }
 #endif

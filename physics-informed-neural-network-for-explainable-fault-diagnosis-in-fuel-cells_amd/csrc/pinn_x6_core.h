@@ -61,10 +61,26 @@ __device__ __forceinline__ int swz(int row) { return (0x78 >> (2 * ((row >> 2) &
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Stash stores of the chain: non-temporal.  The 7.7 GB a step writes are read back much later (the d pre-activations only
+// by the weight-gradient kernels); written with the default policy they push the 1-MB packed weights that every CU
+// streams from its XCD's L2 out of it (chain 4.68 -> 4.28 ms at 1e6 rows; PINN_ABL_PLAINSTORE = the old policy).
+#ifdef PINN_ABL_PLAINSTORE
+#define PINN_STASH_ST(p, v) (*(p) = (v))
+#else
+#define PINN_STASH_ST(p, v) __builtin_nontemporal_store((v), (p))
+#endif
+#ifdef PINN_ABL_NTRING
+#define PINN_RING_AUX 2
+#else
+#define PINN_RING_AUX 0
+#endif
+#ifdef PINN_ABL_PRIO
+#define PINN_ABL_PRIO_YOUNG (threadIdx.x >= 256 && blockDim.x == 512)
+#endif
 #ifdef PINN_X6_STAMP
 // diagnostic build only: per-wave cycle sums of the segments of a slab step (first phase, second phase,
 // wait + barrier), read back with pinn_x6_debug_read()
-__device__ unsigned long long g_x6_stamps[8 * 4];
+__device__ unsigned long long g_x6_stamps[8 * 8];
 __device__ __forceinline__ unsigned long long stamp() {
   unsigned long long t;
   __builtin_amdgcn_sched_barrier(0);
@@ -87,7 +103,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 // its pieces one at a time between the MFMAs of its multiply phase (slab_mfma), where the issue slot is free.
 struct Pipe6 {
 #ifdef PINN_X6_STAMP
-  unsigned long long seg[4], last;
+  unsigned long long seg[8], last;
 #endif
   __amdgpu_buffer_rsrc_t rsrc;   // the packed weights as a raw buffer: copy 0 at byte 0, copies 1, 2 at +copy_bytes
   unsigned copy_bytes;
@@ -120,6 +136,22 @@ struct Pipe6 {
     char* dst = lds + buf * kSlabBytes + copy * (kSlabBytes / 3) + rb * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, voff, soff, 0, 0);
   }
+  // The same for a matrix whose shape is a compile-time constant with at least WAVES 16-row blocks per copy (NRB_LOG =
+  // log2 of them): piece WAVES * J + wave is (copy, row block) = (static, static + wave), so the scalar offset is the
+  // per-wave, per-matrix term mbase = wave_base<KP_LOG>(m) plus compile-time terms: 3 scalar instructions instead of 12.
+  template <int KP_LOG>
+  __device__ __forceinline__ unsigned wave_base(const Mat& m) const { return 2u * m.off + (((unsigned)wave * 32u) << KP_LOG); }
+  template <int KP_LOG, int WAVES, int NRB_LOG, int J>
+  __device__ __forceinline__ void piece_s(unsigned mbase, int g, int buf) {
+    constexpr int q = WAVES * J, copy = q >> NRB_LOG, rb0 = q & ((1 << NRB_LOG) - 1);
+    static_assert(WAVES <= (1 << NRB_LOG) && copy < 3, "piece_s: shape not separable");
+    mbase = __builtin_amdgcn_readfirstlane(mbase);     // (wave-uniform by construction; hipcc does not always see it)
+    asm volatile("" : "+s"(mbase));   // (or every piece's offset is precomputed outside the row loop: register pressure)
+    const unsigned voff = (lane_row2 << KP_LOG) + lane_kq8;
+    const unsigned soff = mbase + (unsigned)copy * copy_bytes + 64u * (unsigned)g + ((unsigned)(rb0 * 32) << KP_LOG);
+    char* dst = lds + buf * kSlabBytes + wave * 1024 + copy * (kSlabBytes / 3) + rb0 * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, voff, soff, 0, 0);
+  }
   // slab 0 of the sequence
   template <int KP_LOG, int WAVES = 8>
   __device__ __forceinline__ void prime(const Mat& first) {
@@ -130,10 +162,20 @@ struct Pipe6 {
     __syncthreads();           // (drains the DMA: vmcnt(0) + barrier)
   }
   __device__ __forceinline__ const char* cur() const { return lds + par * kSlabBytes; }
-  // end of a slab step: the barrier's vmcnt(0) retires this wave's pieces of the next slab; past it every wave is
-  // done reading the current slab and the next one is complete
+  // end of a slab step: past the barrier every wave is done reading the current slab and the next one is complete.
+  // kYoung = vector-memory operations this wave has issued AFTER its last LDS-DMA of the step (the training kernels'
+  // stash stores, batched behind the step's last MFMA): vmcnt counts in issue order, so waiting for all but the
+  // kYoung youngest retires every DMA of the step and leaves the stores in flight across the barrier.  With
+  // __syncthreads() (vmcnt(0)) every step paid the full HBM write latency of its stores: 1.2 of the chain's 4.6 ms.
+  template <int kYoung = 0>
   __device__ __forceinline__ void advance() {
-    __syncthreads();
+#ifdef PINN_ABL_VM0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kYoung) : "memory");
+#endif
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     par ^= 1;
   }
 };
@@ -211,6 +253,10 @@ __device__ __forceinline__ void mfma6(f32x4& acc, const AFrag3& a, const Frag3& 
 // waves 4-7 running each chunk before instead of after its tile's MFMAs; whole-phase staggering of the two waves.)
 template <int MT, int NTOUT, typename V, typename D>
 __device__ __forceinline__ void slab_pair(f32x4 (&acc)[NTOUT], const Frag3& b, unsigned addr, AFrag3& a0, AFrag3& a1, V&& vchunk, D&& dma) {
+#ifdef PINN_ABL_PRIO
+  if constexpr (MT == 0) { if (PINN_ABL_PRIO_YOUNG) __builtin_amdgcn_s_setprio(1); }
+  if constexpr (MT == NTOUT / 2 && NTOUT >= 4) { if (PINN_ABL_PRIO_YOUNG) __builtin_amdgcn_s_setprio(0); }
+#endif
   wait_a3<3>(a0);                                   // a1 (issued after a0) may still be in flight
   mfma6(acc[MT], a0, b);
   __builtin_amdgcn_sched_barrier(0);
@@ -317,22 +363,34 @@ __device__ __forceinline__ void prep_micro(Prep& s, f32x4& v0, f32x4& v1, const 
     }
   } else if constexpr (k == 1) {
     if constexpr (!kBits && par == 0) philox_rounds5<5>(s, d.seed_lo, d.seed_hi);
-  } else {
+  } else if constexpr (k < 6) {
     constexpr int r = k - 2;
     const float a0 = tanh_f32(v0[r]), a1 = tanh_f32(v1[r]);
     const bool k0 = kBits ? ((s.keep >> r) & 1u) != 0 : keep_draw<par, 0, r>(s, ld.thr);
     const bool k1 = kBits ? ((s.keep >> (4 + r)) & 1u) != 0 : keep_draw<par, 1, r>(s, ld.thr);
     const float h0 = k0 ? a0 * ld.scale : 0.0f;
     const float h1 = k1 ? a1 * ld.scale : 0.0f;
-    v0[r] = h0; v1[r] = h1;
     split_pair<r>(h0, h1, out);
-    if (sp) {
-      sp[r * 16] = stash_value(h0, k0);
-      sp[(16 + r) * 16] = stash_value(h1, k1);
-    }
+    // training: the registers keep the value the stash will hold (stored by micro-step 6, behind the step's last DMA)
+    v0[r] = sp ? stash_value(h0, k0) : h0;
+    v1[r] = sp ? stash_value(h1, k1) : h1;
     if (kDot) {
       const float t = fmaf(wp32[4 * c.kq + r], h0, wp32[16 + 4 * c.kq + r] * h1);
       up += dot_on ? t : 0.0f;
+    }
+  } else {
+    if (sp) {
+#ifdef PINN_ABL_WIDESTORE      // timing experiment only: same bytes, same 2-KB region, two 16-B stores per lane (WRONG layout)
+      float* q = sp - (4 * c.kq * 16 + (c.lane & 15)) + c.lane * 8;
+      *reinterpret_cast<f32x4*>(q) = v0;
+      *reinterpret_cast<f32x4*>(q + 4) = v1;
+#else
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        PINN_STASH_ST(sp + r * 16, v0[r]);
+        PINN_STASH_ST(sp + (16 + r) * 16, v1[r]);
+      }
+#endif
     }
   }
 }
@@ -343,22 +401,45 @@ __device__ __forceinline__ void prep_micro(Prep& s, f32x4& v0, f32x4& v1, const 
 // whose raw values are this layer's acc[0], acc[1] -- final once the last slab's first tile pair is through, so
 // those steps sit in slots >= 1.  KPM / KPN: log2 row stride of this / the next matrix; NPM / NPN: (an upper bound
 // of) their 1-KB pieces per slab.
-template <int P, int NG, int NTOUT, int KPM, int KPN, int NPM, int NPN, bool kHasOut, int WAVES = 8, typename FI, typename FO>
+template <int P, int NG, int NTOUT, int KPM, int KPN, int NPM, int NPN, bool kHasOut, int WAVES = 8, int kStIn = 0, int kStOut = 0, int NRBM = -1,
+          typename FI, typename FO>
 __device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], Pipe6& pipe, const Mat& mine, const Mat& next, int lane, Prep& st,
-                                         FI&& prep_in, FO&& prep_out) {
+                                         FI&& prep_in, FO&& prep_out, bool out_on = true) {
   constexpr int kSlots = NTOUT / 2, kPerDma = (48 / WAVES + kSlots - 1) / kSlots;      // <= 48 / WAVES pieces per wave and slab
   // VALU chunks: one per tile (NTOUT per slab).  The six micro-steps of the next group go to chunks
   // kFirst + k * (NTOUT - kFirst) / 6; acc[0], acc[1] (the next layer's group 0) are final from chunk 2 on.
+  // Micro-step 6 (training: the group's kStIn / kStOut stash stores) is the last thing before the barrier.
   constexpr int kFirst = kHasOut ? 2 : 0, kAvail = NTOUT - kFirst;
   static_assert(kAvail >= 1, "no chunk left for the next layer's group 0");
+  // NRBM >= 0: this matrix has the static shape 16 << NRBM rows x (32 NG): the cheap piece addressing (Pipe6::piece_s)
+  static_assert(NRBM < 0 || NPM == (3 << NRBM), "NRBM does not match the piece count");
+#ifdef PINN_ABL_GENERIC_PIECE
+  constexpr int kNrbm = -1;
+#else
+  constexpr int kNrbm = NRBM;
+#endif
+  const unsigned mine_base = kNrbm >= 0 ? pipe.wave_base<KPM>(mine) : 0u;
   static_for<NG>([&](auto gc) {
     constexpr int g = decltype(gc)::value;
     // the next slab: K-group g + 1 of this matrix, or K-group 0 of the next one
     auto dma = [&](auto slotc) {
+#ifdef PINN_ABL_ROTDMA
+      // experiment: the eight waves issue their pieces in different pair-slots (rotated by the wave index), so that the
+      // CU's 64-B/clk vector-memory path sees one or two pieces per slot instead of eight at once
+      if constexpr (NTOUT == 16 && WAVES == 8) {
+        const int j = (decltype(slotc)::value - pipe.wave) & 7;
+        if constexpr (g + 1 < NG) { if (WAVES * j < NPM) pipe.piece<KPM, WAVES>(mine, g + 1, j, pipe.par ^ 1); }
+        else { if (WAVES * j < NPN) pipe.piece<KPN, WAVES>(next, 0, j, pipe.par ^ 1); }
+        return;
+      }
+#endif
       static_for<kPerDma>([&](auto qc) {
         constexpr int j = decltype(slotc)::value * kPerDma + decltype(qc)::value;
         if constexpr (g + 1 < NG) {
-          if constexpr (WAVES * j < NPM) pipe.piece<KPM, WAVES>(mine, g + 1, j, pipe.par ^ 1);
+          if constexpr (WAVES * j < NPM) {
+            if constexpr (kNrbm >= 0) pipe.piece_s<KPM, WAVES, kNrbm, j>(mine_base, g + 1, pipe.par ^ 1);
+            else pipe.piece<KPM, WAVES>(mine, g + 1, j, pipe.par ^ 1);
+          }
         } else {
           if constexpr (WAVES * j < NPN) pipe.piece<KPN, WAVES>(next, 0, j, pipe.par ^ 1);
         }
@@ -367,17 +448,21 @@ __device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], Pipe6& pipe, const
     // the next group's fragments
     auto vchunk = [&](auto cc) {
       constexpr int c = decltype(cc)::value;
-      static_for<6>([&](auto kc) {
+      static_for<7>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        if constexpr (kFirst + k * kAvail / 6 == c) {
+        if constexpr ((k < 6 && kFirst + k * kAvail / 6 == c) || (k == 6 && c == NTOUT - 1)) {
           if constexpr (g + 1 < NG) prep_in(IC<g + 1>{}, IC<k>{}, st.buf[(P + g + 1) & 1]);
           else if constexpr (kHasOut) prep_out(IC<k>{}, st.buf[(P + g + 1) & 1]);
         }
       });
     };
     slab_mfma<NTOUT>(acc, st.buf[(P + g) & 1], pipe.cur(), lane, vchunk, dma);
-    pipe.advance();
-    PINN_STAMP(pipe, (NTOUT == 16 ? 0 : NTOUT == 8 ? 1 : 2));
+    PINN_STAMP(pipe, (NTOUT == 16 ? 0 : NTOUT == 8 ? 1 : 2));      // step body; then (below) 4 + type = wait + barrier
+    // (out_on: wave-uniform; false when prep_out issues nothing -- the count must never exceed the stores really issued)
+    if constexpr (g + 1 < NG) pipe.advance<kStIn>();
+    else if constexpr (kHasOut && kStOut > 0) { if (out_on) pipe.advance<kStOut>(); else pipe.advance<0>(); }
+    else pipe.advance<0>();
+    PINN_STAMP(pipe, 4 + (NTOUT == 16 ? 0 : NTOUT == 8 ? 1 : 2));
   });
 }
 
@@ -407,6 +492,7 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
                                                 const DropDev& d, const RowCtx& c, const f32x4& xa, const f32x4& xb, float& u, float& z,
                                                 const StashX* sx = nullptr, f32x4* v2_out = nullptr) {
   constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32;
+  constexpr int kSt = TRAIN ? 8 : 0;      // stash stores per prepared group (behind the step's last DMA)
   const int lane = c.lane, kq = c.kq;
   const SmallLayout S{L.H, L.nh};
   const PackLayout K{L.H, L.nh};
@@ -421,7 +507,7 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
   {   // group 0 of the first matrix layer's input: nothing to hide it under
     const LayerDrop ld0 = layer_drop(d, c.mode, 0);
     float* sp = TRAIN ? sx->act(0, H, lane) : nullptr;
-    static_for<6>([&](auto kc) { prep_micro<kBits, true, decltype(kc)::value, 0>(st, h[0], h[1], d, c, ld0, 0, wp, up, ll == 0, st.buf[0], sp); });
+    static_for<7>([&](auto kc) { prep_micro<kBits, true, decltype(kc)::value, 0>(st, h[0], h[1], d, c, ld0, 0, wp, up, ll == 0, st.buf[0], sp); });
   }
 #pragma unroll 1
   for (int l = 1; l < L.nh; ++l) {
@@ -433,7 +519,7 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
     float* sp_in = TRAIN ? sx->act(l - 1, H, lane) : nullptr;
     float* sp_out = TRAIN ? sx->act(l, H, lane) : nullptr;
     static_assert(NP % 2 == 0 && (NP / 2) % 2 == 0, "the forward layers keep the fragment buffer parity");
-    layer_x6<0, NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true, WAVES>(
+    layer_x6<0, NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true, WAVES, kSt, kSt, clog2(H / 16)>(
         acc, pipe, mine, next, lane, st,
         [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value;
@@ -453,7 +539,7 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
     const LayerDrop ld_in = layer_drop(d, c.mode, ll), ld_out = layer_drop(d, c.mode, L.nh);
     float* sp_in = TRAIN ? sx->act(ll, H, lane) : nullptr;
     float* sp_out = TRAIN ? tiled_ptr(sx->v1, sx->t16, H / 2, lane) : nullptr;
-    layer_x6<0, NP, NT2, KPW, KPV1, 3 * H / 32, 3 * H / 64, true, WAVES>(
+    layer_x6<0, NP, NT2, KPW, KPV1, 3 * H / 32, 3 * H / 64, true, WAVES, kSt, kSt, (WAVES <= H / 32 ? clog2(H / 32) : -1)>(
         v1, pipe, m_v0, m_v1, lane, st,
         [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value;
@@ -479,7 +565,7 @@ __device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* s
       // the backward pass starts with Wv1^T: [H/2][H/4], row stride padded to 64
       constexpr int KPT1 = clog2((H / 4 + 63) & ~63);
       const Mat m_t1{(unsigned)K.wv1t(), clog2(H / 32)};
-      layer_x6<0, NP / 2, NT4, KPV1, KPT1, 3 * H / 64, 3 * H / 32, false, WAVES>(v2, pipe, m_v1, m_t1, lane, st, prep_in, [&](auto, Frag3&) {});
+      layer_x6<0, NP / 2, NT4, KPV1, KPT1, 3 * H / 64, 3 * H / 32, false, WAVES, kSt, 0>(v2, pipe, m_v1, m_t1, lane, st, prep_in, [&](auto, Frag3&) {});
     } else {
       layer_x6<0, NP / 2, NT4, KPV1, KPW, 3 * H / 64, 3 * H / 16, false, WAVES>(v2, pipe, m_v1, first_mat<H>(K), lane, st, prep_in, [&](auto, Frag3&) {});
     }
@@ -509,8 +595,8 @@ struct StashRing {
   int lane;
   __device__ __forceinline__ void fetch(const float* block, int buf) const {
     const char* src = reinterpret_cast<const char*>(block) + lane * 16;
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + buf * 2048), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + 1024), (lptr_t)(lds + buf * 2048 + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + buf * 2048), 16, 0, PINN_RING_AUX);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + 1024), (lptr_t)(lds + buf * 2048 + 1024), 16, 0, PINN_RING_AUX);
   }
   // feature 16 b + 4 kq + r of the block, this lane's row
   __device__ __forceinline__ float read(int buf, int b, int r) const {
@@ -519,21 +605,31 @@ struct StashRing {
 };
 
 // micro-step k of a backward group: raw d0, d1 = d loss / d h (two 16-feature blocks) -> d pre-activation in place,
-// stashed for the weight-gradient kernels (dsp) and split for the next matrix.  h = post-dropout activation from
+// split for the next matrix (k = 2 .. 5) and stashed for the weight-gradient kernels (dsp; k = 6).  h = post-dropout activation from
 // the stash copy in LDS: dropped <=> h == 0, a = h / scale, d pre = d h * scale * (1 - a^2).
 template <int k>
 __device__ __forceinline__ void bprep_micro(Frag3& out, f32x4& d0, f32x4& d1, const StashRing& ring, int buf, float* dsp, float scale,
                                             float inv_scale) {
-  if constexpr (k >= 2) {
+  if constexpr (k >= 2 && k < 6) {
     constexpr int r = k - 2;
     const float h0 = ring.read(buf, 0, r), h1 = ring.read(buf, 1, r);
     const float a0 = h0 * inv_scale, a1 = h1 * inv_scale;
     const float g0 = d0[r] * (scale * (1.0f - a0 * a0)), g1 = d1[r] * (scale * (1.0f - a1 * a1));
     const float p0 = h0 != 0.0f ? g0 : 0.0f, p1 = h1 != 0.0f ? g1 : 0.0f;
     d0[r] = p0; d1[r] = p1;
-    dsp[r * 16] = p0;
-    dsp[(16 + r) * 16] = p1;
     split_pair<r>(p0, p1, out);
+  } else if constexpr (k == 6) {      // the group's eight stores, behind the step's last DMA (Pipe6::advance<8>)
+#ifdef PINN_ABL_WIDESTORE
+    float* q = dsp - (4 * (ring.lane >> 4) * 16 + (ring.lane & 15)) + ring.lane * 8;
+    *reinterpret_cast<f32x4*>(q) = d0;
+    *reinterpret_cast<f32x4*>(q + 4) = d1;
+#else
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      PINN_STASH_ST(dsp + r * 16, d0[r]);
+      PINN_STASH_ST(dsp + (16 + r) * 16, d1[r]);
+    }
+#endif
   }
 }
 
@@ -587,11 +683,11 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     const LayerDrop ldv = layer_drop(d, mode, nh);
     const float scale = ldv.scale, inv_scale = 1.0f / scale;
     float* dsp = tiled_ptr(sx.dv1, sx.t16, H / 2, lane);
-    layer_x6<0, NG1, NT2, KPT1, KPT0, 3 * H / 32, 3 * H / 16, true, WAVES>(
+    layer_x6<0, NG1, NT2, KPT1, KPT0, 3 * H / 32, 3 * H / 16, true, WAVES, 0, 8, (WAVES <= H / 32 ? clog2(H / 32) : -1)>(
         dpv1, pipe, m_t1, m_t0, lane, st,
         [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
-          if constexpr (k >= 2 && 2 * g + 1 < NT4) split_pair<k - 2>(v2[2 * g][k - 2], v2[2 * g + 1][k - 2], out);
+          if constexpr (k >= 2 && k < 6 && 2 * g + 1 < NT4) split_pair<k - 2>(v2[2 * g][k - 2], v2[2 * g + 1][k - 2], out);
         },
         [&](auto kc, Frag3& out) {
           constexpr int k = decltype(kc)::value;
@@ -616,7 +712,7 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     float* dsp = tiled_ptr(sx.dv1, sx.t16, H / 2, lane);
     float* dsp_o = sx.dact(nh - 1, H, lane);
     const Mat next = nh > 1 ? Mat{(unsigned)K.wt(nh - 1), clog2(H / 16)} : m_first;
-    layer_x6<P1, NP / 2, NT, KPT0, KPW, 3 * H / 16, 3 * H / 16, true, WAVES>(
+    layer_x6<P1, NP / 2, NT, KPT0, KPW, 3 * H / 16, 3 * H / 16, true, WAVES, 8, 8, clog2(H / 16)>(
         dh, pipe, m_t0, next, lane, st,
         [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
@@ -629,7 +725,8 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
             if constexpr (k == 0) fetch_block(NP / 2 + 1);
             bprep_micro<k>(out, dh[0], dh[1], ring, (NP / 2) & 1, dsp_o, scale_o, inv_scale_o);
           }
-        });
+        },
+        nh > 1);
   }
 
   // ---- hidden layers nh-1 .. 1: d h_{l-1} = W_l^T d pre_l
@@ -643,7 +740,7 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     float* dsp_o = sx.dact(l - 1, H, lane);
     const int base = NP / 2 + (nh - 1 - l) * NP;           // stash block index of this layer's group 0
     const Mat mine{(unsigned)K.wt(l), clog2(H / 16)}, next = l > 1 ? Mat{(unsigned)K.wt(l - 1), clog2(H / 16)} : m_first;
-    layer_x6<P1, NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true, WAVES>(
+    layer_x6<P1, NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true, WAVES, 8, 8, clog2(H / 16)>(
         acc, pipe, mine, next, lane, st,
         [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
@@ -656,7 +753,8 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
             if constexpr (k == 0) fetch_block(base + NP + 1);
             bprep_micro<k>(out, acc[0], acc[1], ring, (base + NP) & 1, dsp_o, scale_o, inv_scale_o);
           }
-        });
+        },
+        l > 1);
 #pragma unroll
     for (int t = 0; t < NT; ++t) dh[t] = acc[t];
   }

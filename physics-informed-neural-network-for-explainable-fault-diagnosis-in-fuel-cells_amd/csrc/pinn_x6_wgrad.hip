@@ -11,6 +11,13 @@
 // Same slices / slabs / bias and vector-head sums as wgrad_kernel (pinn_train.hip); layer 0 (IN = 8) stays there.
 #include <cstdlib>
 #include "pinn_x6_core.h"
+#ifdef PINN_ABL_NTLOAD
+#define PINN_WG_LD4(p) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p))
+#define PINN_WG_AUX 2
+#else
+#define PINN_WG_LD4(p) (*reinterpret_cast<const f32x4*>(p))
+#define PINN_WG_AUX 0
+#endif
 #include "pinn_wgrad_args.h"
 
 namespace pinn {
@@ -49,14 +56,14 @@ __device__ __forceinline__ void wgrad_load(Raw<TI, TJ>& f, const WgradArgs& a, l
   const float* pP = a.P + ((t * a.OUT + i0 + i) * 16 + 8 * hh);
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti) {
-    f.a[ti][0] = *reinterpret_cast<const f32x4*>(pP + ti * 512);
-    f.a[ti][1] = *reinterpret_cast<const f32x4*>(pP + ti * 512 + 4);
+    f.a[ti][0] = PINN_WG_LD4(pP + ti * 512);
+    f.a[ti][1] = PINN_WG_LD4(pP + ti * 512 + 4);
   }
   const float* pQ = a.Q + ((t * a.IN + j0 + i) * 16 + 8 * hh);
 #pragma unroll
   for (int tj = 0; tj < TJ; ++tj) {
-    f.b[tj][0] = *reinterpret_cast<const f32x4*>(pQ + tj * 512);
-    f.b[tj][1] = *reinterpret_cast<const f32x4*>(pQ + tj * 512 + 4);
+    f.b[tj][0] = PINN_WG_LD4(pQ + tj * 512);
+    f.b[tj][1] = PINN_WG_LD4(pQ + tj * 512 + 4);
   }
 }
 
@@ -95,8 +102,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
   constexpr bool kDeep = TI * TJ < 16;
   struct Side { f32x4 r[kDeep ? TI : 1][2], s2[2], s1[2]; };      // operands of the vector-head sums (prefetched iff kDeep)
   const bool want_r = row_sums && a.dvr, want_q = col_sums && a.dvq;
-  auto load_r = [&](long long t, int ti, int sg) { return *reinterpret_cast<const f32x4*>(a.R + ((t * a.OUT + i0 + i) * 16 + 8 * hh) + ti * 512 + sg * 4); };
-  auto load_s = [&](const float* sv, long long t, int sg) { return *reinterpret_cast<const f32x4*>(sv + t * 16 + 8 * hh + sg * 4); };
+  auto load_r = [&](long long t, int ti, int sg) { return PINN_WG_LD4(a.R + ((t * a.OUT + i0 + i) * 16 + 8 * hh) + ti * 512 + sg * 4); };
+  auto load_s = [&](const float* sv, long long t, int sg) { return PINN_WG_LD4(sv + t * 16 + 8 * hh + sg * 4); };
   auto fetch = [&](Raw<TI, TJ>& f, Side& sd, long long t) {
     if (t >= t_end) t = t_end - 1;
     wgrad_load<TI, TJ>(f, a, t, i0, j0, hh, i);
@@ -255,8 +262,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_d_kernel(WgradArgs a) {
 #pragma unroll
     for (int f = 0; f < kFrags; ++f) {
       const float* src = f < TI ? pP + f * 512 : pQ + (f - TI) * 512;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + f * 2048), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + 4), (lptr_t)(st + f * 2048 + 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + f * 2048), 16, 0, PINN_WG_AUX);
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + 4), (lptr_t)(st + f * 2048 + 1024), 16, 0, PINN_WG_AUX);
     }
   };
   auto read = [&](Raw<TI, TJ>& r, int stage) {

@@ -24,7 +24,7 @@ for src, extra in _build.SOURCES:
     sp = os.path.join(_build.CSRC, src)
     if src in files:
         obj = os.path.join(out, src[:-4] + ".o")
-        cmd = [_build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", sp, "-o", obj] + extra + flags
+        cmd = [_build._hipcc()] + _build.BASE_FLAGS + ["-c", sp, "-o", obj] + extra + flags
         procs.append((cmd, subprocess.Popen(cmd)))
     else:
         obj = sp[:-4] + ".o"
