@@ -30,7 +30,15 @@ Extra legs reported in the same JSON line (rank 0):
                   M = 174 400 MAC.  Peak: f32x6 executes 6 bf16 MFMA FLOP per algorithmic FLOP, so
                   its ceiling is the dense bf16 peak / 6 = 416.7 TFLOP/s; exact fp32: 157.3 TFLOP/s.
    cpu_baseline : the CPU oracle's train_dnn step (torch CPU, autograd, torch-bernoulli masks,
-                  Adam) on a bounded row sample, host cores of this box (N = 1 only)
+                  Adam) on the host cores of this box (N = 1 only): a 1e5-row sample (median of 3)
+                  AND the headline's 1e6 rows (1 warm-up on the sample + 2 timed steps), and the
+                  MC-dropout unit of work both as the reference counts it (2T predict calls x 2 forwards)
+                  and as useful work (1 eval + T stochastic forwards)
+   configs      : BASELINE.json's other configurations, each a small leg of its own (rank 0, N = 1):
+                  "1" the reference's CPU-runnable case (1e4 + 1e3 rows, train_dnn(100), mc_times = 32) on the
+                  GPU and through the CPU oracle; "4_step" one rank's 65 536-row minibatch step with its
+                  per-kernel breakdown; "5" the wide net [8,1024x4,1] (262 144 rows, T = 1024 on a row slice);
+                  "residuals" the HBM-bound physics row pass in GB/s against the 8 TB/s roof
 """
 import argparse
 import json
@@ -72,47 +80,272 @@ def parse():
     ap.add_argument("--no-mc", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=100_000)
+    ap.add_argument("--no-cpu-full", action="store_true", help="skip the CPU baseline at the headline's full row count (~1 min)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the legs for BASELINE configs 1, 4, 5 and the residual pass")
     ap.add_argument("--precision", default="f32x6", choices=sorted(PRECISIONS), help="arithmetic of the headline measurement")
     ap.add_argument("--only", action="store_true", help="skip the extra legs in the other precisions")
     ap.add_argument("--no-bf16", action="store_true", help="skip the extra bf16/fp32-mixed leg")
     return ap.parse_args()
 
 
-def cpu_baseline(rows):
-    """CPU oracle train_dnn step (the reference's arithmetic, restated) on `rows` rows."""
+def _cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            return next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        return ""
+
+
+def cpu_baseline(rows, full_rows, mc_passes):
+    """CPU oracle (the reference's arithmetic, restated; test infrastructure used here only as the timed baseline):
+    train_dnn step on `rows` rows (median of 3 after a warm-up) and on `full_rows` rows (2 timed steps), and the
+    MC-dropout forwards at `full_rows` rows."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pinn_oracle as O
     from pinn_amd import synth
-    ds = synth.make_dataset(rows, (), seed=0)
-    x, y = ds[0], ds[1]
     P = O.init_params([8, H, H, H, 1], seed=0)
-    opt = O.AdamState(P)
     gen = torch.Generator().manual_seed(0)
-    times = []
-    for it in range(6):                                  # 1 warm-up + 5 timed repetitions, median (SURVEY 8 D3)
-        t0 = time.perf_counter()
-        masks = [(torch.rand(rows, w, generator=gen) >= 0.2) for w in (H, H, H, H // 2)]   # bernoulli draws, as the reference pays
-        _, _, grads, _, _ = O.nll_loss_and_grads(P, x, y, [0.2] * 4, masks)
-        opt.step(P, grads, 0.01)
-        times.append(time.perf_counter() - t0)
-    best = sorted(times[1:])[len(times[1:]) // 2]
-    # stochastic forward (MC-dropout unit of work)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        for t in range(2):
-            masks = [(torch.rand(rows, w, generator=gen) >= 0.4) for w in (H, H, H, H // 2)]
+
+    def step_time(n, reps, warm):
+        ds = synth.make_dataset(n, (), seed=0)
+        x, y = ds[0], ds[1]
+        opt = O.AdamState(P)
+        times = []
+        for it in range(warm + reps):
+            t0 = time.perf_counter()
+            masks = [(torch.rand(n, w, generator=gen) >= 0.2) for w in (H, H, H, H // 2)]   # bernoulli draws, as the reference pays
+            _, _, grads, _, _ = O.nll_loss_and_grads(P, x, y, [0.2] * 4, masks)
+            opt.step(P, grads, 0.01)
+            times.append(time.perf_counter() - t0)
+        t = sorted(times[warm:])
+        return t[len(t) // 2], x
+
+    t_small, _ = step_time(rows, 3, 1)
+    out = {"value": rows / t_small, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "train_dnn step (fwd+NLL+autograd bwd+Adam, torch-bernoulli masks) of oracle/pinn_oracle.py on %d rows, "
+                     "median of 3 after 1 warm-up; os.cpu_count()=%d; %s" % (rows, os.cpu_count(), _cpu_model_name()),
+           "rows": rows}
+    if full_rows and full_rows > rows:
+        t_full, x = step_time(full_rows, 2, 0)            # (the sample above was the warm-up)
+        out["full_size"] = {"rows": full_rows, "samples_per_s": full_rows / t_full, "seconds_per_step": t_full,
+                            "sample": "the headline's row count, median of 2 steps"}
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            O.mlp_forward(P, x)
+            t_eval = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            masks = [(torch.rand(full_rows, w, generator=gen) >= 0.4) for w in (H, H, H, H // 2)]
             O.mlp_forward(P, x, [0.4] * 4, masks)
-    fwd = (time.perf_counter() - t0) / 2
-    model_name = ""
-    try:
-        with open("/proc/cpuinfo") as f:
-            model_name = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
-    except OSError:
-        pass
-    return {"value": rows / best, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "train_dnn step (fwd+NLL+autograd bwd+Adam, torch-bernoulli masks) of oracle/pinn_oracle.py on %d rows, "
-                      "median of 5 after 1 warm-up; os.cpu_count()=%d; %s" % (rows, os.cpu_count(), model_name),
-            "mc_fwd_passes_per_s": rows / fwd}
+            t_st = time.perf_counter() - t0
+        T = mc_passes
+        # 01:1442-1464: T eval predict() + T stochastic predict(), each = net_u + a discarded net_f_V (second DNN forward)
+        out["mc"] = {"rows": full_rows, "passes": T, "eval_forward_s": t_eval, "stochastic_forward_s": t_st,
+                     "useful_fwd_passes_per_s": full_rows * T / (t_eval + T * t_st),
+                     "reference_faithful_fwd_passes_per_s": full_rows * T / (2 * T * t_eval + 2 * T * t_st),
+                     "note": "passes/s counts the T stochastic row-passes get_MC_samples returns statistics of; the reference "
+                             "executes 4T forwards for them (2T predict calls x 2), useful work is T + 1; extrapolated from one "
+                             "eval and one stochastic forward at %d rows" % full_rows}
+        out["mc_fwd_passes_per_s"] = out["mc"]["useful_fwd_passes_per_s"]
+    return out
+
+
+def _events(fn, reps, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps       # ms
+
+
+def leg_config1(with_cpu):
+    """BASELINE configs[0] -- the reference's own CPU-runnable case: 1e4 normal (+ 1e3 fault) synthetic rows,
+    [8,256,256,256,1], train_dnn(100) (01:2143 at 2.5 % of its 4001 epochs), get_MC_samples(mc_times=32) on all
+    1.1e4 rows (01:2156): wall time of the public surface on the GPU, and of the CPU oracle doing the same work."""
+    import pinn_amd
+    from pinn_amd import synth
+    ds = synth.make_dataset(10_000, (1000,), seed=0)
+    torch.manual_seed(0)
+    m = pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, H, H, H, 1], ds[4], ds[5], p=0.2, logvar=True, seed=0)
+    m.verbose = False
+    m.train_dnn(2); pinn_amd.get_MC_samples(m, ds[2][:256], ds[4], mc_times=2, dropout=0.4); torch.cuda.synchronize()     # warm-up
+    t0 = time.perf_counter(); m.train_dnn(100); torch.cuda.synchronize(); t_train = time.perf_counter() - t0
+    t0 = time.perf_counter(); pinn_amd.get_MC_samples(m, ds[2], ds[4], mc_times=32, dropout=0.4); t_mc = time.perf_counter() - t0
+    n_tr, n_te = ds[0].shape[0], ds[2].shape[0]
+    r = {"workload": "BASELINE configs[0]: %d train rows, 100 train_dnn epochs, mc_times=32 on %d rows" % (n_tr, n_te),
+         "gpu": {"train_dnn_100_s": t_train, "train_samples_per_s": 100 * n_tr / t_train, "us_per_step": t_train / 100 * 1e6,
+                 "mc32_s": t_mc, "mc_fwd_passes_per_s": 32 * n_te / t_mc}}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pinn_oracle as O
+        P = O.init_params([8, H, H, H, 1], seed=0)
+        opt = O.AdamState(P)
+        gen = torch.Generator().manual_seed(0)
+        x, y = ds[0], ds[1]
+        t0 = time.perf_counter()
+        for _ in range(100):
+            masks = [(torch.rand(n_tr, w, generator=gen) >= 0.2) for w in (H, H, H, H // 2)]
+            _, _, grads, _, _ = O.nll_loss_and_grads(P, x, y, [0.2] * 4, masks)
+            opt.step(P, grads, 0.01)
+        c_train = time.perf_counter() - t0
+        xt = ds[2]
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            O.mlp_forward(P, xt)
+            for _ in range(32):
+                O.mlp_forward(P, xt, [0.4] * 4, [(torch.rand(n_te, w, generator=gen) >= 0.4) for w in (H, H, H, H // 2)])
+            c_useful = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for _ in range(64):                      # the reference: 32 eval predict() + 32 stochastic predict(), 2 forwards each
+                O.mlp_forward(P, xt)
+            for _ in range(64):
+                O.mlp_forward(P, xt, [0.4] * 4, [(torch.rand(n_te, w, generator=gen) >= 0.4) for w in (H, H, H, H // 2)])
+            c_faithful = time.perf_counter() - t0
+        r["cpu_oracle"] = {"cores": torch.get_num_threads(), "train_dnn_100_s": c_train, "train_samples_per_s": 100 * n_tr / c_train,
+                           "mc32_useful_s": c_useful, "mc32_reference_faithful_s": c_faithful,
+                           "mc_fwd_passes_per_s_useful": 32 * n_te / c_useful, "mc_fwd_passes_per_s_reference_faithful": 32 * n_te / c_faithful}
+    return r
+
+
+def leg_config4_step(dev):
+    """BASELINE configs[3], one rank's share of a step: a 65 536-row minibatch (of a 524 288-row global batch over 8
+    ranks) through train_dnn's step -- chain, weight gradients, slab reduction, Adam -- with the per-kernel times and
+    what is left between them (launch gaps; the all-reduce of the 0.70 MB bucket is not part of a 1-GPU run)."""
+    import ctypes
+    import pinn_amd
+    from pinn_amd import _lib, synth
+    from pinn_amd.model import _ptr, _stream
+    rows, n_global = 65_536, 524_288
+    ds = synth.make_dataset(rows, (), seed=3)
+    torch.manual_seed(0)
+    m = pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, H, H, H, 1], ds[4], ds[5], p=0.2, logvar=True, seed=0, n_global=n_global)
+    m.verbose = False
+    m.dnn.train()
+    lib = m._lib
+    xd, yd, flat = m.x.detach(), m.u.reshape(-1), m.dnn.flat_params()
+    work = m._workspace(rows)
+    drop = m.dnn.dropout_struct(3, 0)
+    loss = torch.empty(4, dtype=torch.float64, device=dev)
+
+    def phase(ph):
+        return lambda: _lib.check(lib.pinn_mlp_train_grads_phases(
+            ctypes.byref(m.dnn._net), _ptr(flat), _ptr(xd), _ptr(yd), rows, n_global, ctypes.byref(drop), _ptr(m.dnn._flat_grad),
+            _ptr(loss), _ptr(work), work.numel(), _stream(), ph), "phases")
+
+    def adam():
+        _lib.check(lib.pinn_adam_step(_ptr(flat), _ptr(m.dnn._flat_grad), _ptr(m._adam_m), _ptr(m._adam_v), flat.numel(), 1e-9, 1, _stream()),
+                   "adam")
+
+    def step():
+        m.train_step_grads(xd, yd, 0, n_global)
+        adam()
+    ms = {"chain": _events(phase(1), 20), "wgrad": _events(phase(2), 20), "finalize": _events(phase(4), 20), "adam": _events(adam, 20)}
+    ms_step = _events(step, 50, warm=5)
+    ksum = sum(ms.values())
+    return {"workload": "BASELINE configs[3], one rank: %d-row minibatch of a %d-row global batch, train_dnn step" % (rows, n_global),
+            "ms_per_step": ms_step, "samples_per_s_per_gpu": rows / ms_step * 1e3, "kernels_ms": ms, "kernel_sum_ms": ksum,
+            "step_minus_kernel_sum_ms": ms_step - ksum,       # (each phase timed alone carries its own weight re-pack launch: can be < 0)
+            "mfma_frac_of_step": STEP_FLOP_PER_ROW * rows / (ms_step * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 6.0)}
+
+
+def leg_config5(dev):
+    """BASELINE configs[4] on one GPU: wide net [8,1024,1024,1024,1024,1] (M = 3 810 560 MAC/row), 262 144 rows:
+    training-gradient call (chain + weight gradients + reduction) and MC-dropout with T = 1024 on a 16 384-row slice,
+    f32x6 arithmetic; MFMA fraction against 2.5 PFLOP/s / 6."""
+    import ctypes
+    from pinn_amd import _lib, layout
+    lib = _lib.load()
+    Hw, nhw, rows, mc_rows, T = 1024, 4, 262_144, 16_384, 1024
+    Mw = 8 * Hw + (nhw - 1) * Hw * Hw + Hw + Hw * Hw // 2 + Hw * Hw // 8 + Hw // 4
+    offs, total = layout.param_offsets(8, Hw, nhw)
+    g = torch.Generator().manual_seed(1)
+    fp = torch.zeros(total)
+    for name, shape, off in offs:
+        n = 1
+        for d in shape:
+            n *= d
+        fan_in = shape[1] if len(shape) == 2 else Hw
+        fp[off:off + n] = (torch.rand(n, generator=g) * 2 - 1) / (fan_in ** 0.5)
+    fp = fp.to(dev)
+    x = torch.rand(rows, 8, device=dev) * 2 - 1
+    y = torch.rand(rows, device=dev)
+    net = _lib.Net(8, Hw, nhw, _lib.PREC_F32X6, None)
+    packed = torch.empty(lib.pinn_packed_bytes(ctypes.byref(net)), dtype=torch.uint8, device=dev)
+    net.d_packed = packed.data_ptr()
+    d = _lib.Dropout()
+    d.mode = _lib.DROP_PHILOX
+    for l in range(nhw + 1):
+        d.p[l] = 0.2
+    d.seed, d.stream, d.row_offset, d.d_bits = 1, 2, 0, None
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    wb = lib.pinn_train_workspace_bytes(ctypes.byref(net), rows)
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    grads = torch.empty(total, device=dev)
+    loss = torch.zeros(4, dtype=torch.float64, device=dev)
+
+    def phase(ph):
+        return lambda: _lib.check(lib.pinn_mlp_train_grads_phases(ctypes.byref(net), P(fp), P(x), P(y), rows, rows, ctypes.byref(d), P(grads),
+                                                                  P(loss), P(work), wb, st(), ph), "wide train")
+    t_all = _events(phase(7), 3, warm=1)
+    t_chain, t_wg = _events(phase(1), 3, warm=1), _events(phase(2), 3, warm=1)
+    u, lv = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    t_fwd = _events(lambda: _lib.check(lib.pinn_mlp_forward(ctypes.byref(net), P(fp), P(x), rows, ctypes.byref(d), P(u), P(lv), st()), "wide fwd"),
+                    3, warm=1)
+    out = torch.empty(3, mc_rows, device=dev)
+    for l in range(nhw + 1):
+        d.p[l] = 0.4
+    xs = x[:mc_rows].contiguous()
+    mc = lambda: _lib.check(lib.pinn_mc_dropout(ctypes.byref(net), P(fp), P(xs), mc_rows, ctypes.byref(d), T, P(out[0]), P(out[1]), P(out[2]), st()),
+                            "wide mc")
+    t_mc = _events(mc, 1, warm=0)
+    peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+    del work
+    return {"workload": "BASELINE configs[4] on one GPU: [8,1024x4,1] (M = %d MAC/row), %d rows; MC-dropout T = %d on %d rows" % (Mw, rows, T, mc_rows),
+            "train": {"ms": t_all, "samples_per_s": rows / t_all * 1e3, "chain_ms": t_chain, "wgrad_ms": t_wg,
+                      "mfma_frac": 6 * Mw * rows / (t_all * 1e-3) / 1e12 / peak},
+            "forward": {"ms": t_fwd, "mfma_frac": 2 * Mw * rows / (t_fwd * 1e-3) / 1e12 / peak},
+            "mc_dropout": {"seconds": t_mc * 1e-3, "fwd_passes_per_s": mc_rows * T / (t_mc * 1e-3),
+                           "mfma_frac": 2 * Mw * mc_rows * (T + 1) / (t_mc * 1e-3) / 1e12 / peak},
+            "peak_TFLOPs": peak, "workspace_GB": wb / 1e9}
+
+
+def leg_residuals(dev):
+    """The HBM-bound part of the path: one iteration of a physics-parameter stage = a pass over the
+    stage's row cache (pinn_residuals_cached: 24 B/row for the voltage model) and over the raw rows (pinn_residuals:
+    40 B/row), at 1e6 and 1e7 rows -- algorithmic bytes / time against the 8 TB/s HBM3E peak."""
+    import ctypes
+    from pinn_amd import _lib
+    lib = _lib.load()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    aff = _lib.Affine()
+    for c in range(8):
+        aff.x_scale[c] = 0.01
+    aff.y_scale = 0.5
+    lam = torch.tensor([0.167897923477715, 2.36682075851268e-06, 2.43414469188443, 1.0] + [10.0] * 5 + [5.0, -1.559, 197.715, 1.2, 2.0, 0.5, 200.0, 1.0],
+                       device=dev)
+    sums = torch.zeros(_lib.NSUMS, dtype=torch.float64, device=dev)
+    work = torch.empty(lib.pinn_residuals_workspace_bytes(), dtype=torch.uint8, device=dev)
+    res = []
+    for n in (1_000_000, 10_000_000):
+        x = torch.rand(n, 8, device=dev) * 2 - 1
+        y = torch.rand(n, device=dev)
+        cache = torch.empty(6 * n, dtype=torch.float32, device=dev)
+        _lib.check(lib.pinn_residuals_prepare(P(x), P(y), P(y), ctypes.byref(aff), P(lam), _lib.RES_V, n, P(cache), st()), "prepare")
+        t_c = _events(lambda: _lib.check(lib.pinn_residuals_cached(P(cache), ctypes.byref(aff), P(lam), _lib.RES_V, n, P(sums), P(work), work.numel(),
+                                                                   st()), "cached"), 50, warm=3)
+        t_r = _events(lambda: _lib.check(lib.pinn_residuals(P(x), P(y), P(y), ctypes.byref(aff), P(lam), _lib.RES_V, n, None, 0, P(sums), P(work),
+                                                            work.numel(), st()), "residuals"), 50, warm=3)
+        for name, t, b in (("residuals_cached_kernel (V stage, 24 B/row)", t_c, 24), ("residuals_kernel (V stage from the rows, 40 B/row)", t_r, 40)):
+            gbps = b * n / (t * 1e-3) / 1e9
+            res.append({"kernel": name, "rows": n, "us": t * 1e3, "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s",
+                        "frac": gbps / 8000.0})
+        del x, y, cache
+    return res
 
 
 def main():
@@ -170,7 +403,7 @@ def main():
         step_no[0] += 1
         # ---- train_dnn step (01:949-955)
         loss = model.train_step_grads(xd, yd, model.row_offset, n_global)
-        dp.allreduce_grads(model.dnn._flat_grad_full, loss, model._group)
+        dp.allreduce_grads(model.dnn._flat_grad_full, model._group)
         _lib.check(lib.pinn_adam_step(_ptr(flat), _ptr(model.dnn._flat_grad), _ptr(model._adam_m), _ptr(model._adam_v),
                                       flat.numel(), 0.01, step_no[0], _stream()), "adam")
         # ---- one iteration of each physics-parameter stage (01:1008-1055, 1107-1151, 1354-1391, 1204-1274)
@@ -311,9 +544,32 @@ def main():
             out[name] = o
         model.dnn.set_precision(args.precision)
 
+    out["config"]["backend"] = dist.get_backend() if world > 1 else "none (single process)"
+    out["config"]["world_size"] = world
+    out["config"]["rows_per_rank"] = [rows] * world
+    # the HBM roof next to the MFMA one: DESIGN bytes of a step (not the 36 B/row the algorithm needs) -- the activation
+    # stash (3.84 KB/row) and the d pre-activations (3.84 KB/row) written by the chain, the stash read back by it and both
+    # read by the weight-gradient kernels -- over the same times; which roof binds is the larger fraction
+    r = out["roofline"]
+    chain_bytes, wgrad_bytes = (36 + 3 * 3840 + 2 * 384) * rows, (2 * 3840 + 32 + 8) * rows
+    out["roofline_hbm_design"] = {
+        "bound": "hbm", "unit": "GB/s", "peak": 8000.0,
+        "chain": {"bytes": chain_bytes, "achieved": chain_bytes / (r["ms"] * 1e-3) / 1e9, "frac": chain_bytes / (r["ms"] * 1e-3) / 1e9 / 8000.0},
+        "wgrad": {"bytes": wgrad_bytes, "achieved": wgrad_bytes / (r["wgrad"]["ms"] * 1e-3) / 1e9,
+                  "frac": wgrad_bytes / (r["wgrad"]["ms"] * 1e-3) / 1e9 / 8000.0},
+        "step": {"bytes": chain_bytes + wgrad_bytes, "achieved": (chain_bytes + wgrad_bytes) / (out["ms_per_step"] * 1e-3) / 1e9,
+                 "frac": (chain_bytes + wgrad_bytes) / (out["ms_per_step"] * 1e-3) / 1e9 / 8000.0},
+        "note": "design bytes: stash written once (h and d pre, 3.84 KB/row each + heads), h read back by the chain, both read once by the "
+                "weight-gradient kernels; algorithmic bytes are 36 B/row (roofline.hbm_algorithmic_GBps)"}
+    if rank == 0 and world == 1 and not args.no_configs:
+        del stage_cache
+        model._work.clear()
+        torch.cuda.empty_cache()
+        out["configs"] = {"4_step": leg_config4_step(dev), "5": leg_config5(dev), "residuals": leg_residuals(dev),
+                          "1": leg_config1(not args.no_cpu)}
     if rank == 0:
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_rows)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_rows, 0 if args.no_cpu_full else rows, args.mc_passes)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bf16_kernel(FwdArgs a, const 
         a.o1[lrow] = logf(softplus_f32(z) + 1e-6f);
       }
     } else {
-      float u_eval = 0.f, s1 = 0.f, s2 = 0.f, sl = 0.f;
+      float u_eval = 0.f, mean = 0.f, m2 = 0.f, sl = 0.f;
 #pragma unroll 1
       for (int t = -1; t < a.n_passes; ++t) {
         c.mode = (t < 0) ? PINN_DROP_NONE : a.drop.mode;
@@ -97,16 +97,13 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_bf16_kernel(FwdArgs a, const 
         if (t < 0) {
           u_eval = u;
         } else {
-          const float du = u - u_eval;
-          s1 += du;
-          s2 = fmaf(du, du, s2);
+          welford_update(mean, m2, u - u_eval, 1.0f / (float)(t + 1));      // population variance of the passes: m2 / T
           sl += logf(softplus_f32(z) + 1e-6f);
         }
       }
       if (valid && lane < 16) {
         const float inv_t = 1.0f / (float)a.n_passes;
-        const float m = s1 * inv_t;
-        const float var = fmaxf(s2 * inv_t - m * m, 0.0f);
+        const float var = m2 * inv_t;
         a.o0[lrow] = u_eval;
         a.o1[lrow] = expf(0.5f * (sl * inv_t));
         a.o2[lrow] = sqrtf(var);

@@ -406,6 +406,15 @@ __device__ __forceinline__ unsigned activate_pair(f32x4& v0, f32x4& v1, const Dr
   return keep;
 }
 
+// Running moments of the MC-dropout passes (01:1486, np.var with ddof = 0): Welford's update on du = u_t - u_eval.
+// The one-pass form E[du^2] - E[du]^2 cancels when the passes nearly coincide (spread << |mean shift|): a row whose
+// passes differed by 1e-4 of their common offset lost all digits of e_u.  k = 1-based pass count, inv_k = 1 / k.
+__device__ __forceinline__ void welford_update(float& mean, float& m2, float x, float inv_k) {
+  const float d = x - mean;
+  mean = fmaf(d, inv_k, mean);
+  m2 = fmaf(d, x - mean, m2);
+}
+
 // tanh only (no dropout module after this layer)
 __device__ __forceinline__ void activate_tanh(f32x4& v) {
 #pragma unroll

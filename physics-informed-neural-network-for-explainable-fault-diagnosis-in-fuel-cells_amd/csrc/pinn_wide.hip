@@ -229,8 +229,9 @@ struct HeadArgs {
   long long wp_off, bp_off, wv2_off, bv2_off;
   int mode;
   float* o0; float* o1;     // mode 0: u, logvar; mode 1: pred_mean
-  float* accum;             // modes 1, 2: [4][chunk rows]: u_eval, sum du, sum du^2, sum logvar
+  float* accum;             // modes 1, 2: [4][chunk rows]: u_eval, running mean of du, Welford m2 of du, sum logvar
   long long accum_stride;
+  int pass;                 // mode 2: 0-based stochastic pass index
 };
 __global__ __launch_bounds__(256) void wide_heads_kernel(HeadArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane >> 4;
@@ -258,9 +259,10 @@ __global__ __launch_bounds__(256) void wide_heads_kernel(HeadArgs a) {
         a.o0[lrow] = u;
         a.accum[lrow] = u; a.accum[a.accum_stride + lrow] = 0.f; a.accum[2 * a.accum_stride + lrow] = 0.f; a.accum[3 * a.accum_stride + lrow] = 0.f;
       } else {
-        const float du = u - a.accum[lrow];
-        a.accum[a.accum_stride + lrow] += du;
-        a.accum[2 * a.accum_stride + lrow] += du * du;
+        float mean = a.accum[a.accum_stride + lrow], m2 = a.accum[2 * a.accum_stride + lrow];
+        welford_update(mean, m2, u - a.accum[lrow], 1.0f / (float)(a.pass + 1));
+        a.accum[a.accum_stride + lrow] = mean;
+        a.accum[2 * a.accum_stride + lrow] = m2;
         a.accum[3 * a.accum_stride + lrow] += lv;
       }
     }
@@ -270,8 +272,7 @@ __global__ __launch_bounds__(256) void wide_mc_finalize_kernel(const float* accu
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float inv_t = 1.0f / (float)n_passes;
-  const float m = accum[stride + i] * inv_t;
-  const float var = fmaxf(accum[2 * stride + i] * inv_t - m * m, 0.0f);
+  const float var = accum[2 * stride + i] * inv_t;          // Welford m2 / T
   a_u[i] = expf(0.5f * (accum[3 * stride + i] * inv_t));
   e_u[i] = sqrtf(var);
 }
@@ -432,7 +433,7 @@ int launch_forward_wide(const pinn_net_t* net, const FwdArgs& fa, bool mc, void*
       la.bias_off = L.bv1(); la.layer = nh + 1;
       launch_wide_layer<EPI_TANH>(la, grid_l, st);
       HeadArgs ha{fa.params, cur, v2, n, H, L.wp(), L.bp(), L.wv2(), L.bv2(), mc ? (pass < 0 ? 1 : 2) : 0,
-                  fa.o0 + r0, mc ? nullptr : fa.o1 + r0, accum, kWideChunk};
+                  fa.o0 + r0, mc ? nullptr : fa.o1 + r0, accum, kWideChunk, pass < 0 ? 0 : pass};
       hipLaunchKernelGGL(wide_heads_kernel, dim3(grid_s), dim3(256), 0, st, ha);
       if (!mc) break;
     }

@@ -382,32 +382,30 @@ class PhysicsInformedNN():
         flat, grad = self.dnn.flat_params(), self.dnn._flat_grad
         step = 0
         loss_sums = None
-        if batch_size is None or batch_size >= n:
-            batches = [(0, n, self.n_global)]
-        else:       # minibatches: each normalised by its GLOBAL size (sum over ranks)
-            counts = {}
-            batches = []
-            for s in range(0, n, batch_size):
-                e = min(n, s + batch_size)
-                if e - s not in counts:
-                    counts[e - s] = _dp.global_count(e - s, self.x.device, self._group)
-                batches.append((s, e, counts[e - s]))
+        n_norm = max(1, self.n_global)
+        # the schedule has the same length on every rank (empty batches included): one gradient all-reduce per entry
+        batches = _dp.batch_schedule(n, batch_size, self.x.device, self._group)
         for epoch in range(nIter):
             lr = 0.01 * 0.8 ** (epoch // 1000)
             for (s, e, n_norm) in batches:
-                xb, yb = (x, y) if (s, e) == (0, n) else (x[s:e], y[s:e])
-                loss_sums = self.train_step_grads(xb, yb, self.row_offset + s, n_norm)
-                _dp.allreduce_grads(self.dnn._flat_grad_full, loss_sums, self._group)
+                if e > s:
+                    xb, yb = (x, y) if (s, e) == (0, n) else (x[s:e], y[s:e])
+                    loss_sums = self.train_step_grads(xb, yb, self.row_offset + s, n_norm)
+                else:       # a rank without rows in this batch: zero gradient, same dropout-stream position, same collective
+                    self._step_counter += 1
+                    self.dnn._flat_grad_full.zero_()
+                    loss_sums = torch.zeros(4, dtype=torch.float64, device=self.x.device)
+                _dp.allreduce_grads(self.dnn._flat_grad_full, self._group)
                 step += 1
                 rc = self._lib.pinn_adam_step(_ptr(flat), _ptr(grad), _ptr(self._adam_m), _ptr(self._adam_v), flat.numel(),
                                               lr, step, _stream())
                 _lib.check(rc, "pinn_adam_step")
-            if epoch % 1000 == 0:
-                ls = loss_sums.cpu().numpy()
+            if epoch % 1000 == 0 and loss_sums is not None:
+                ls = _dp.allreduce_sums(loss_sums.clone(), self._group).cpu().numpy()      # fp64, only when a line is printed
                 lr_next = 0.01 * 0.8 ** ((epoch + 1) // 1000)
                 self._log(f' {epoch:5d}  | {(ls[0] + 0.01 * ls[1]) / n_norm:10.3e} | {ls[2] / n_norm:10.3e} | {lr_next:8.1e}')
         if loss_sums is not None:
-            ls = loss_sums.cpu().numpy()
+            ls = _dp.allreduce_sums(loss_sums.clone(), self._group).cpu().numpy()
             self.last_loss = (ls[0] + 0.01 * ls[1]) / n_norm
             self._log(f'DNN training done, final loss: {self.last_loss:.3e}')
 

@@ -1,6 +1,7 @@
 """CPU, world_size 2, gloo: the data-parallel scheme of pinn_amd.dp (row shards, sums divided by the
-GLOBAL row count, ONE all_reduce(SUM) of the flat bucket with the loss in its tail, replicated Adam,
-masks keyed by global row) reproduces the single-process full-batch step.  The per-rank gradient
+GLOBAL row count, ONE all_reduce(SUM) of the flat gradient bucket per step, loss sums in fp64 only when
+logged, replicated Adam, masks keyed by global row) reproduces the single-process full-batch step, and the
+minibatch schedule has the same length on every rank whatever the shard sizes.  The per-rank gradient
 engine here is the CPU oracle (test infrastructure); on the GPU the same dp functions wrap the HIP engine."""
 import os
 import socket
@@ -55,7 +56,8 @@ def _worker(rank, world, port, q):
     for step in (1, 2, 3):
         g, sums = _local_step(P, x, y, lo, hi, N, step)
         bucket = torch.cat([g, torch.zeros(dp.LOSS_TAIL)])
-        dp.allreduce_grads(bucket, sums, None)
+        dp.allreduce_grads(bucket, None)
+        dp.allreduce_sums(sums, None)
         g = bucket[:-dp.LOSS_TAIL]
         grads, k = [], 0
         for p in P:
@@ -66,6 +68,15 @@ def _worker(rank, world, port, q):
     s = torch.arange(32, dtype=torch.float64) * (rank + 1)
     dp.allreduce_sums(s, None)
     assert dp.global_count(hi - lo, torch.device("cpu")) == N
+    # minibatch schedule: uneven shards (rank 0: 150 rows, rank 1: 151) at batch 50 -> 4 batches on BOTH ranks,
+    # the last one empty on rank 0; global sizes 100, 100, 100, 1; a rank without rows still gets the full schedule
+    sched = dp.batch_schedule(hi - lo, 50, torch.device("cpu"))
+    assert len(sched) == 4 and [c for _, _, c in sched] == [100, 100, 100, 1]
+    assert sched[3][:2] == ((150, 150) if rank == 0 else (150, 151))
+    sched0 = dp.batch_schedule(0 if rank == 0 else 120, 50, torch.device("cpu"))
+    assert len(sched0) == 3 and [c for _, _, c in sched0] == [50, 50, 20]
+    assert dp.batch_schedule(hi - lo, None, torch.device("cpu")) == [(0, hi - lo, N)]
+    assert dp.batch_schedule(hi - lo, 151, torch.device("cpu")) == [(0, hi - lo, N)]
     q.put((rank, _flat(P).numpy(), losses, s.numpy()))
     dist.destroy_process_group()
 

@@ -80,7 +80,7 @@ def test_mc_dropout_x6(lib, N, T):
     pm, au, eu = O.mc_dropout(P, x, p, T, mf)
     np.testing.assert_allclose(o[0], np.asarray(pm).reshape(-1), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(o[1], np.asarray(au).reshape(-1), rtol=1e-4)
-    np.testing.assert_allclose(o[2], np.asarray(eu).reshape(-1), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(o[2], np.asarray(eu).reshape(-1), rtol=1e-3, atol=2e-6)      # atol: the fp32 forward noise of u_t itself
 
 
 def _check_grads(got_flat, want_list, H, nh, rtol, atol_scale=1e-6):
@@ -225,7 +225,7 @@ def test_mc_dropout_wide(lib):
     pm, au, eu = O.mc_dropout(P, x, p, T, mf)
     np.testing.assert_allclose(o[0], np.asarray(pm).reshape(-1), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(o[1], np.asarray(au).reshape(-1), rtol=1e-4)
-    np.testing.assert_allclose(o[2], np.asarray(eu).reshape(-1), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(o[2], np.asarray(eu).reshape(-1), rtol=1e-3, atol=2e-6)      # atol: the fp32 forward noise of u_t itself
 
 
 @pytest.mark.parametrize("H,nh,N,mode", [(512, 2, 300, 1), (1024, 4, 200, 1), (512, 1, 129, 0)])
