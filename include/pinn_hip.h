@@ -139,6 +139,15 @@ int pinn_residuals_prepare(const float* d_x, const float* d_u, const float* d_y,
 int pinn_residuals_cached(const float* d_cache, const pinn_affine_t* aff, const float* d_lambda, unsigned flags,
                           long long n_rows, double* d_sums, void* d_work, size_t work_bytes, void* stream);
 
+/* net_f_T (01:767-867): the Euler energy-balance thermal model, row t-1 -> t, one fused pass (HBM-bound: 36 B/row read,
+ * 12 B/row written).  d_u = the DNN's eval-mode output on the same rows (normalised units; row t uses u[t-1], as the
+ * reference runs the net on X[:-1]).  Row 0 of the series has no predecessor: T_pred = T_out (01:857).  Under row
+ * sharding a rank passes the LAST row of the previous shard (8 floats) and its DNN output (1 float) as d_x_halo /
+ * d_u_halo (device pointers; both NULL on the shard that starts the series) -- a one-row halo, no collective.
+ * Outputs: the three tuple elements (f_T = T_out - T_pred, T_pred, T_out), float[n_rows] each.  Reads lambda_T1..T4. */
+int pinn_net_f_t(const float* d_x, const float* d_u, const float* d_x_halo, const float* d_u_halo, const pinn_affine_t* aff,
+                 const float* d_lambda, long long n_rows, float* d_f, float* d_t_pred, float* d_t_real, void* stream);
+
 /* ---- the network ------------------------------------------------------------------------
  * Architecture [n_in=8, hidden x n_hidden, 1] + variance head hidden -> hidden/2 -> hidden/4 -> 1
  * (01:389-438).  Parameters live in ONE flat float32 device buffer in state_dict order,

@@ -153,6 +153,9 @@ def main():
     m.dnn.eval()
     out = {"x": xe.numpy(), "y": ye.numpy()}
     out.update(scaler_arrays("sx.", sx)); out.update(scaler_arrays("sy.", sy))
+    # the net behind u_eval and behind net_f_T's electrochemical term (01:826-838): stored so that the HIP net_f_T can be
+    # compared element for element with the reference's TE.* tuples
+    out.update({"w." + k: v for k, v in state(m.dnn).items()})
     with torch.no_grad():
         out["u_eval"] = m.net_u(m.x)[0].numpy()
     lam_sets = [dict(), dict(lambda_1=0.25, lambda_2=1.1e-6, lambda_3=3.3, lambda_T1=0.02, lambda_T3=-0.11, lambda_T5=31.0,

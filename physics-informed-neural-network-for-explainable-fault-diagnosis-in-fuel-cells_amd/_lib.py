@@ -75,6 +75,8 @@ _SIGS = {
     "pinn_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_int, c_void_p]),
     "pinn_residuals_prepare": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(Affine), c_void_p, c_uint, c_ll, c_void_p, c_void_p]),
     "pinn_residuals_cached": (c_int, [c_void_p, ctypes.POINTER(Affine), c_void_p, c_uint, c_ll, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pinn_net_f_t": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Affine), c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
+                             c_void_p]),
     "pinn_results_assemble": (c_int, [c_void_p, c_void_p, ctypes.POINTER(Affine), ctypes.c_double, ctypes.c_double, c_int, c_void_p, c_int,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p]),
 }

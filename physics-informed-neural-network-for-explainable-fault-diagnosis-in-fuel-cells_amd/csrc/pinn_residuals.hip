@@ -619,6 +619,51 @@ static int row_blocks(long long n_rows) {
 }
 static bool one_stage_flag(unsigned flags) { return flags == PINN_RES_V || flags == PINN_RES_T || flags == PINN_RES_H || flags == PINN_RES_O; }
 
+
+// ---------------------------------------------------------------------------------------
+// net_f_T (01:767-867): the Euler energy balance row t-1 -> t.  Row t reads the de-normalised current, coolant flow,
+// inlet and outlet temperature and the DNN's eval-mode voltage of row t - 1 (a halo of ONE row: under row sharding the
+// caller passes the last row of the previous shard as x_halo / u_halo) and its own outlet temperature:
+//   I = (I/270 + 1e-5) 270;  V_rev = 1.229 - 0.0009 ((T_out + 273.15) - 298.15);  V_cell = denorm(u) / 5
+//   Q_el = (I V_rev - I V_cell) lT4;  Q_cool = (m + 1e-6) 4180 (T_out - T_in) lT1;  Q_rad = 20 * 0.2 (T_out - 25) lT3
+//   T_pred[t] = T_out[t-1] + ((Q_el - Q_cool - Q_rad) / lT2) 0.1;   T_pred[0] = T_out[0] (01:857);   f = T_out - T_pred
+// every float op rounded separately, in the reference's order (this file is built with -ffp-contract=off).
+// 32 B/row + 4 B/row (u) read -- the previous row's line is an L1/L2 hit --, 12 B/row written: HBM-bound.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void net_f_T_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                           const float* __restrict__ x_halo, const float* __restrict__ u_halo, AffineDev aff,
+                                                           const float* __restrict__ lambdas, long long n_rows, float* __restrict__ f_out,
+                                                           float* __restrict__ t_pred, float* __restrict__ t_real) {
+  const float lT1 = lambdas[PINN_LT1], lT2 = lambdas[PINN_LT2], lT3 = lambdas[PINN_LT3], lT4 = lambdas[PINN_LT4];
+  for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < n_rows; row += (long long)gridDim.x * blockDim.x) {
+    const float T_out = denorm(x[row * 8 + 5], aff.x_min[5], aff.x_scale[5]);
+    float pred = T_out;                                      // first row of the series (01:857)
+    const float* xp = row > 0 ? x + (row - 1) * 8 : x_halo;
+    if (xp != nullptr) {
+      const float4 pa = reinterpret_cast<const float4*>(xp)[0];
+      const float4 pb = reinterpret_cast<const float4*>(xp)[1];
+      const float un = row > 0 ? u[row - 1] : u_halo[0];
+      const float r0 = denorm(pa.x, aff.x_min[0], aff.x_scale[0]);
+      const float m_cool = denorm(pa.y, aff.x_min[1], aff.x_scale[1]) + 1e-6f;
+      const float T_in = denorm(pa.z, aff.x_min[2], aff.x_scale[2]);
+      const float T_prev = denorm(pb.y, aff.x_min[5], aff.x_scale[5]);
+      const float i5 = r0 / 270.0f + 0.00001f;
+      const float I_tot = i5 * 270.0f;
+      const float Tk = T_prev + 273.15f;
+      const float V_rev = 1.229f - 0.0009f * (Tk - 298.15f);
+      const float V_cell = denorm(un, aff.y_min, aff.y_scale) / 5.0f;
+      const float Q_el = (I_tot * V_rev - I_tot * V_cell) * lT4;
+      const float Q_cool = ((m_cool * 4180.0f) * (T_prev - T_in)) * lT1;
+      const float Q_rad = ((20.0f * 0.2f) * (T_prev - 25.0f)) * lT3;
+      const float dT = ((Q_el - Q_cool) - Q_rad) / lT2;
+      pred = T_prev + dT * 0.1f;
+    }
+    f_out[row] = T_out - pred;
+    t_pred[row] = pred;
+    t_real[row] = T_out;
+  }
+}
+
 }  // namespace
 
 extern "C" size_t pinn_residuals_workspace_bytes(void) { return (size_t)kMaxBlocks * PINN_NSUMS * sizeof(double); }
@@ -707,6 +752,24 @@ extern "C" int pinn_residuals_cached(const float* d_cache, const pinn_affine_t* 
   hipLaunchKernelGGL(residuals_cached_kernel, dim3(blocks), dim3(kThreads), 0, st, d_cache, affine_dev(aff), d_lambda, flags, n_rows,
                      (double*)d_work);
   hipLaunchKernelGGL(residuals_finalize, dim3(1), dim3(1024), 0, st, (const double*)d_work, blocks, d_sums);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PINN_OK : (int)e;
+}
+
+extern "C" int pinn_net_f_t(const float* d_x, const float* d_u, const float* d_x_halo, const float* d_u_halo, const pinn_affine_t* aff,
+                            const float* d_lambda, long long n_rows, float* d_f, float* d_t_pred, float* d_t_real, void* stream) {
+  if (n_rows < 0 || !aff || !d_lambda || (n_rows > 0 && (!d_x || !d_f || !d_t_pred || !d_t_real))) return PINN_E_ARG;
+  if (n_rows > 1 && !d_u) return PINN_E_ARG;
+  if ((d_x_halo == nullptr) != (d_u_halo == nullptr)) return PINN_E_ARG;
+  if (n_rows == 0) return PINN_OK;
+  (void)hipGetLastError();
+  AffineDev a;
+  for (int c = 0; c < 8; ++c) { a.x_min[c] = aff->x_min[c]; a.x_scale[c] = aff->x_scale[c]; }
+  a.y_min = aff->y_min; a.y_scale = aff->y_scale; a.vn_scale = aff->vn_scale; a.vn_min = aff->vn_min;
+  long long want = (n_rows + kThreads - 1) / kThreads;
+  const int blocks = (int)(want > kMaxBlocks ? kMaxBlocks : want);
+  hipLaunchKernelGGL(net_f_T_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, d_x, d_u, d_x_halo, d_u_halo, a, d_lambda, n_rows,
+                     d_f, d_t_pred, d_t_real);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;
 }

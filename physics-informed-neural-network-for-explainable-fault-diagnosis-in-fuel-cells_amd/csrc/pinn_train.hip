@@ -404,38 +404,64 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
   }
 }
 
-// grads[e] = sum_s slab[s][e] in fixed order; scalar head biases and the loss sums from the chain partials
+// grads[e] = sum_s slab[s][e] in a fixed order; scalar head biases and the loss sums from the chain partials.
+// A workgroup owns 32 groups of four consecutive parameters; its 256 threads are 8 slice lanes x 32 groups: lane q adds
+// the slices q, q + 8, ... of its group (8 independent 16-B loads in flight), the eight partial sums meet in LDS and are
+// added in lane order -- the same tree on every run (bitwise reproducible; no float atomics).  (One thread per group
+// walking all 256 slices was 32 dependent rounds of loads: 64 us whatever the row count, a fifth of a 65 536-row step.)
+constexpr int kFinLanes = 8, kFinGroups = 32;
 __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restrict__ slabs, int n_slices, long long total,
                                                             const double* __restrict__ loss_part, int n_parts,
                                                             long long off_bp, long long off_bv2, float* __restrict__ grads,
                                                             double* __restrict__ loss_out) {
-  // four consecutive parameters per thread (16-B loads; every tensor starts on a multiple of 4 floats, so the two scalar
-  // head biases sit at the start of a group whose other three floats are padding)
-  const long long e = 4 * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
+  __shared__ f32x4 part[kFinLanes][kFinGroups];
+  const int g = threadIdx.x & (kFinGroups - 1), q = threadIdx.x / kFinGroups;
+  // every tensor starts on a multiple of 4 floats, so the two scalar head biases sit at the start of a group whose other
+  // three floats are padding
+  const long long e = 4 * ((long long)blockIdx.x * kFinGroups + g);
+  f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
   if (e < total) {
+    int k = q;
+    for (; k + 7 * kFinLanes < n_slices; k += 8 * kFinLanes) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(slabs + (long long)(k + j * kFinLanes) * total + e);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; k < n_slices; k += kFinLanes) s += *reinterpret_cast<const f32x4*>(slabs + (long long)k * total + e);
+  }
+  part[q][g] = s;
+  __syncthreads();
+  if (q == 0 && e < total) {
     if (e == off_bp || e == off_bv2) {
       grads[e + 1] = 0.0f; grads[e + 2] = 0.0f; grads[e + 3] = 0.0f;       // [e] itself: the loss-sum block below
     } else {
-      // 8 independent 16-B loads in flight, added in slice order (fixed order -> bitwise reproducible)
-      f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
-      int k = 0;
-      for (; k + 8 <= n_slices; k += 8) {
-        f32x4 v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(slabs + (long long)(k + q) * total + e);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s += v[q];
-      }
-      for (; k < n_slices; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (long long)k * total + e);
+      for (int j = 1; j < kFinLanes; ++j) s += part[j][g];
       *reinterpret_cast<f32x4*>(grads + e) = s;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x < kLossTerms) {
-    double t = 0.0;
-    for (int b = 0; b < n_parts; ++b) t += loss_part[(long long)b * kLossTerms + threadIdx.x];
-    if (threadIdx.x < 4) loss_out[threadIdx.x] = t;    // nll sum, |logvar| sum, (y-u)^2 sum, (sum du)
-    if (threadIdx.x == 3) grads[off_bp] = (float)t;    // d loss / d b_p  = sum du
-    if (threadIdx.x == 4) grads[off_bv2] = (float)t;   // d loss / d bv_2 = sum dz
+  if (blockIdx.x == 0) {
+    // the chain's per-workgroup loss partials (<= 1024 x kLossTerms doubles): strided over the 256 threads, then a fixed
+    // shuffle / LDS tree (one thread walking them serially cost ~50 us of dependent L2 latency)
+    __shared__ double lred[4][kLossTerms];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kLossTerms; ++k) {
+      double v = 0.0;
+      for (int b = threadIdx.x; b < n_parts; b += 256) v += loss_part[(long long)b * kLossTerms + k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) lred[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kLossTerms) {
+      const double t = ((lred[0][threadIdx.x] + lred[1][threadIdx.x]) + lred[2][threadIdx.x]) + lred[3][threadIdx.x];
+      if (threadIdx.x < 4) loss_out[threadIdx.x] = t;    // nll sum, |logvar| sum, (y-u)^2 sum, (sum du)
+      if (threadIdx.x == 3) grads[off_bp] = (float)t;    // d loss / d b_p  = sum du
+      if (threadIdx.x == 4) grads[off_bv2] = (float)t;   // d loss / d bv_2 = sum dz
+    }
   }
 }
 
@@ -595,7 +621,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     b.slabs = (float*)(base + w.off_slabs); b.t16 = w.t16; b.n_slices = w.n_slices;
     if ((rc = launch_train_bf16(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, phases, &grid, stream))) return rc;
     if (phases & PINN_PHASE_REDUCE)
-      hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((L.total() / 4 + 255) / 256)), dim3(256), 0, st, b.slabs, w.n_slices,
+      hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((L.total() / 4 + kFinGroups - 1) / kFinGroups)), dim3(256), 0, st, b.slabs, w.n_slices,
                          L.total(), a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss);
     hipError_t eb = hipGetLastError();
     return eb == hipSuccess ? PINN_OK : (int)eb;
@@ -657,7 +683,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
   }
 
   if (phases & PINN_PHASE_REDUCE)
-    hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, st, slabs, w.n_slices, tot,
+    hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((tot / 4 + kFinGroups - 1) / kFinGroups)), dim3(256), 0, st, slabs, w.n_slices, tot,
                        a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;

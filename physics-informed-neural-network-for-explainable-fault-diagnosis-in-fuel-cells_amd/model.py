@@ -299,34 +299,27 @@ class PhysicsInformedNN():
         c = self._residuals(X, x_scal, _lib.RES_O)
         return self._col(c, "FO"), self._col(c, "ACTO"), self._col(c, "TGTO"), self._col(c, "QO2"), self._col(c, "O2FLOW")
 
-    def net_f_T(self, X, x_scal):
-        """01:767-867: Euler energy balance row t-1 -> t.  Not on the training / results path
-        (SURVEY.md 8(f) F4); evaluated with elementwise device ops on the kernels' outputs."""
+    def net_f_T(self, X, x_scal, halo=None):
+        """01:767-867: Euler energy balance row t-1 -> t -> (f_T, T_out_predicted_full, T_out_real_full), one fused
+        kernel (pinn_net_f_t).  The DNN runs in the caller's train / eval mode on the rows, as the reference runs it on
+        X[:-1] (01:826-830).  `halo` = (x_row [8], u) of the row before X[0] when X is a row shard that does not start
+        the series (device or host tensors; not in the reference, which has no sharding)."""
         xd = self._dev_rows(X)
         n = xd.shape[0]
         dev = xd.device
-        if n < 2:
+        if n < 2 and halo is None:
             z = torch.zeros(n, 1, device=dev)
             return z, z.clone(), z.clone()
-        c = self._residuals(xd, x_scal, _lib.RES_T | _lib.RES_H)
-        u, _ = self.net_u(xd[:-1])
-        a = self._affine(x_scal)
-        V_tot = ((u.double() - a.y_min).float().double() / a.y_scale).float()
-        It = self._col(c, "ITOT")                    # (I/270 + 1e-5) * 270
-        T_out = self._col(c, "TOUT")
-        real12 = ((xd[:, 1:3].double() - torch.tensor(list(a.x_min)[1:3], device=dev)).float().double()
-                  / torch.tensor(list(a.x_scale)[1:3], device=dev)).float()
-        m_cool, T_in = real12[:, 0:1] + 1e-6, real12[:, 1:2]
-        I_prev, m_prev, Tin_prev, Tout_prev = It[:-1], m_cool[:-1], T_in[:-1], T_out[:-1]
-        V_rev = 1.229 - 0.0009 * ((Tout_prev + 273.15) - 298.15)
-        V_single = V_tot / 5.0
-        Q_el = (I_prev * V_rev - I_prev * V_single) * self.lambda_T4.detach()
-        Q_cool = m_prev * 4180.0 * (Tout_prev - Tin_prev) * self.lambda_T1.detach()
-        Q_rad = 20.0 * 0.2 * (Tout_prev - 25.0) * self.lambda_T3.detach()
-        dT = (Q_el - Q_cool - Q_rad) / self.lambda_T2.detach()
-        T_next = Tout_prev + dT * 0.1
-        T_full = torch.cat([T_out[0:1], T_next], dim=0)
-        return T_out - T_full, T_full, T_out
+        u = self.net_u(xd)[0].reshape(-1).contiguous() if n > 0 else None
+        xh = uh = None
+        if halo is not None:
+            xh = torch.as_tensor(halo[0], dtype=torch.float32).reshape(8).to(dev).contiguous()
+            uh = torch.as_tensor(halo[1], dtype=torch.float32).reshape(1).to(dev).contiguous()
+        out = torch.empty(3, n, device=dev, dtype=torch.float32)
+        rc = self._lib.pinn_net_f_t(_ptr(xd), _ptr(u), _ptr(xh), _ptr(uh), ctypes.byref(self._affine(x_scal)), _ptr(self._lambdas()), n,
+                                    _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _stream())
+        _lib.check(rc, "pinn_net_f_t")
+        return out[0].unsqueeze(1), out[1].unsqueeze(1), out[2].unsqueeze(1)
 
     def aleatoric_loss(self, gt, pred_y, logvar):
         """01:916-927."""

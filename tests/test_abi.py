@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def lib():
     import __graft_entry__ as g
+    os.environ.setdefault("PINN_FORCE_BUILD", "0")      # the driver's build() check compiles everything; here: incremental
     g.build()
     from pinn_amd import _lib
     return _lib.load(build_if_missing=False)

@@ -188,3 +188,13 @@ def test_model_statistics_dict():
     assert set(st) == {k[5:] for k in g if k.startswith("stat.")}
     for k, v in st.items():
         np.testing.assert_allclose(v, g["stat." + k], rtol=2e-5, err_msg=k)
+
+
+def test_resid_fixture_weights_reproduce_u_eval():
+    """g_resid.npz stores the net behind its `u_eval` (and behind net_f_T's electrochemical term): the oracle forward of
+    those weights is the stored eval output bit for bit."""
+    g = load_golden("g_resid.npz")
+    P = params_from_golden(g)
+    with torch.no_grad():
+        u, _ = O.mlp_forward(P, torch.from_numpy(g["x"]))
+    assert np.array_equal(u.numpy(), g["u_eval"])
