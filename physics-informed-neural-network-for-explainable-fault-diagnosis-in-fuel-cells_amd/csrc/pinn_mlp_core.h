@@ -406,6 +406,21 @@ __device__ __forceinline__ unsigned activate_pair(f32x4& v0, f32x4& v1, const Dr
   return keep;
 }
 
+// Compute units of the current device, asked once per device (hipGetDeviceProperties costs tens of microseconds: too
+// much for the launch path of a 200-us training step at the reference's data sizes).  One process drives one GPU, but
+// the cache is keyed by the device id anyway.
+static inline int cu_count_cached() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 // Running moments of the MC-dropout passes (01:1486, np.var with ddof = 0): Welford's update on du = u_t - u_eval.
 // The one-pass form E[du^2] - E[du]^2 cancels when the passes nearly coincide (spread << |mean shift|): a row whose
 // passes differed by 1e-4 of their common offset lost all digits of e_u.  k = 1-based pass count, inv_k = 1 / k.

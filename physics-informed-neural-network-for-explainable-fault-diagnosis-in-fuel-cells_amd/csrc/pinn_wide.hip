@@ -21,6 +21,13 @@ constexpr int kWideChunk = 65536;        // rows per pass through the layer kern
 
 enum { EPI_TANH_DROP = 0, EPI_TANH = 1, EPI_BACKWARD = 2 };
 
+// dropout of one 32-feature group with the mask source chosen at run time (wave-uniform): on-chip Philox, or the bit
+// masks a parity test injects (PINN_DROP_BITS: word index (pass * n_rows + row) * words + layer * nb + group, as in the
+// fused kernels; the launchers below pre-offset d.bits per row chunk and pass, so pass = 0 here)
+__device__ __forceinline__ unsigned activate_pair_rt(f32x4& v0, f32x4& v1, const DropDev& d, const RowCtx& c, const LayerDrop ld, int layer, int fp) {
+  return d.mode == PINN_DROP_BITS ? activate_pair<true>(v0, v1, d, c, ld, layer, fp) : activate_pair<false>(v0, v1, d, c, ld, layer, fp);
+}
+
 struct LayerArgs {
   const float* params;       // flat fp32 parameters (biases, init weights)
   const char* packed;        // three bf16 copies
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
         const LayerDrop ldr = layer_drop(a.drop, c.mode, a.layer);
 #pragma unroll
         for (int k = 0; k < kNT / 2; ++k) {
-          const unsigned keep = activate_pair<false>(acc[2 * k], acc[2 * k + 1], a.drop, c, ldr, a.layer, ob * (kNT / 2) + k);
+          const unsigned keep = activate_pair_rt(acc[2 * k], acc[2 * k + 1], a.drop, c, ldr, a.layer, ob * (kNT / 2) + k);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             acc[2 * k][r] = stash_value(acc[2 * k][r], (keep >> r) & 1u);
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(256) void wide_input_kernel(InputArgs a) {
           s = fmaf(w1[0], xb[0], s); s = fmaf(w1[1], xb[1], s); s = fmaf(w1[2], xb[2], s); s = fmaf(w1[3], xb[3], s);
           v[b][r] = s;
         }
-      const unsigned keep = activate_pair<false>(v[0], v[1], a.drop, c, ldr, 0, fp);
+      const unsigned keep = activate_pair_rt(v[0], v[1], a.drop, c, ldr, 0, fp);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         v[0][r] = stash_value(v[0][r], (keep >> r) & 1u);
@@ -382,19 +389,13 @@ size_t wide_scratch_floats(int H) {
   return (size_t)wide::kWideChunk * (2 * (size_t)H + H / 2 + H / 4 + 4);
 }
 
-static int wide_cus() {
-  int cus = 0, dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-  return cus > 0 ? cus : 256;
-}
+static int wide_cus() { return cu_count_cached(); }
 
 // forward / MC-dropout of a wide net: chunks of rows through input -> hidden layers -> variance head -> heads
 int launch_forward_wide(const pinn_net_t* net, const FwdArgs& fa, bool mc, void* stream) {
   using namespace wide;
   hipStream_t st = (hipStream_t)stream;
   const int H = net->hidden, nh = net->n_hidden;
-  if (fa.drop.mode == PINN_DROP_BITS) return PINN_E_ARCH;       // injected masks: fused kernels only
   ParamLayout L{H, nh};
   PackLayout K{H, nh};
   x6::launch_pack_x6(net, fa.params, st);
@@ -414,7 +415,11 @@ int launch_forward_wide(const pinn_net_t* net, const FwdArgs& fa, bool mc, void*
       DropDev d = fa.drop;
       const bool stochastic = mc ? pass >= 0 : fa.drop.mode != PINN_DROP_NONE;
       if (!stochastic) d.mode = PINN_DROP_NONE;
-      const unsigned p = pass < 0 ? 0u : (unsigned)pass;
+      unsigned p = pass < 0 ? 0u : (unsigned)pass;
+      if (d.mode == PINN_DROP_BITS) {      // the masks of this (pass, row chunk): kernels index them from pass 0, row 0
+        d.bits = fa.drop.bits + ((long long)p * fa.n_rows + r0) * d.words;
+        p = 0u;
+      }
       InputArgs ia{fa.params, fa.x + r0 * 8, bufA, n, d.row_offset + r0, H, L.w0(), L.b0(), d, p};
       hipLaunchKernelGGL(wide_input_kernel, dim3(grid_s), dim3(256), 0, st, ia);
       float* cur = bufA; float* nxt = bufB;
@@ -451,7 +456,6 @@ int launch_train_chain_wide(const pinn_net_t* net, const float* d_params, const 
   using namespace wide;
   hipStream_t st = (hipStream_t)stream;
   const int H = net->hidden, nh = net->n_hidden;
-  if (drop.mode == PINN_DROP_BITS) return PINN_E_ARCH;
   ParamLayout L{H, nh};
   PackLayout K{H, nh};
   x6::launch_pack_x6(net, d_params, st);

@@ -12,16 +12,7 @@ struct PackJobs6 {
   long long copy_stride;
 };
 
-static int cu_count_x() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
-}
+static int cu_count_x() { return cu_count_cached(); }
 
 // three bf16 copies (hi, mid, lo with w = hi + mid + lo exactly) of every matrix and its transpose,
 // K permuted inside each 32-group (pack_col_x6)
@@ -159,7 +150,11 @@ int launch_forward_x6(const pinn_net_t* net, const FwdArgs& a, bool mc, void* st
   launch_pack_x6(net, a.params, st);
   const int cus = cu_count_x();
   const long long t128 = (a.n_rows + 127) / 128;
-  static const bool force8 = getenv("PINN_X6_WAVES8") != nullptr;     // measurement: always the 8-wave kernels
+#ifdef PINN_DEBUG_HOOKS
+  static const bool force8 = getenv("PINN_X6_WAVES8") != nullptr;     // measurement builds only: always the 8-wave kernels
+#else
+  constexpr bool force8 = false;
+#endif
   const bool small_n = !force8 && 2 * t128 <= cus;           // 64-row tiles still fit one per CU
   const long long n_tiles = small_n ? (a.n_rows + 63) / 64 : t128;
   const int grid = (int)(n_tiles < cus ? n_tiles : cus);

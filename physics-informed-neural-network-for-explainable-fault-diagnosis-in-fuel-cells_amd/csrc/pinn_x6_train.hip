@@ -138,13 +138,14 @@ int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const fl
   TrainArgsX a{};
   a.params = d_params; a.x = d_x; a.y = d_y; a.n_rows = n_rows; a.n_global = n_global; a.H = net->hidden; a.nh = net->n_hidden;
   a.drop = drop; a.b = b;
-  int cus = 0, dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-  if (cus <= 0) cus = 256;
+  const int cus = cu_count_cached();
   // the stash is padded to whole 128-row tiles: the 64-row kernel covers them too (two tiles each)
   const long long t128 = (n_rows + 127) / 128;
-  static const bool force8 = getenv("PINN_X6_WAVES8") != nullptr;     // measurement: always the 8-wave kernels
+#ifdef PINN_DEBUG_HOOKS
+  static const bool force8 = getenv("PINN_X6_WAVES8") != nullptr;     // measurement builds only: always the 8-wave kernels
+#else
+  constexpr bool force8 = false;
+#endif
   const bool small_n = !force8 && 2 * t128 <= cus;           // 64-row tiles still fit one per CU
   const long long n_tiles = small_n ? 2 * t128 : t128;
   const int grid = (int)(n_tiles < cus ? n_tiles : cus);

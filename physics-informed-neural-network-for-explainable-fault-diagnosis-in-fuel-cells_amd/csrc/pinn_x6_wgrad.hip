@@ -369,7 +369,11 @@ int dispatch_wgrad_x6(const WgradArgs& a, int ns, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int to = a.OUT / 32, ti = a.IN / 32;
   if (a.Q == nullptr || a.IN % 32 || a.OUT % 32) return PINN_E_ARCH;
-  static const bool direct = getenv("PINN_WGRAD_DIRECT") != nullptr;     // measurement: the register-staged kernel everywhere
+#ifdef PINN_DEBUG_HOOKS
+  static const bool direct = getenv("PINN_WGRAD_DIRECT") != nullptr;     // measurement builds only: the register-staged kernel everywhere
+#else
+  constexpr bool direct = false;
+#endif
   if (!direct && !a.dvq && !a.dvr && to % 8 == 0 && ti % 8 == 0) return launch_d<4, 4, 2, 2>(a, ns, st);   // plain layers: deep prefetch
   if (to == 8 && ti == 8) launch<4, 4, 2, 2>(a, ns, st);
   else if (to == 4 && ti == 8) launch<2, 4, 2, 2>(a, ns, st);

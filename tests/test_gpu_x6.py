@@ -250,6 +250,44 @@ def test_train_grads_wide_vs_oracle_autograd(lib, H, nh, N, mode):
     _check_grads(grads, go, H, nh, rtol=2e-4)
 
 
+def test_wide_injected_masks(lib):
+    """Injected-mask mode of the wide path (the deterministic-parity mode of SURVEY.md 9.4, so far fused kernels only):
+    forward, MC-dropout over T passes and the training gradients of [8,512,512,1] replay torch-drawn masks exactly as
+    the oracle applies them."""
+    import hip_helpers as hh
+    from pinn_amd import _lib, synth
+    H, nh, N, T, p = 512, 2, 300, 3, 0.3
+    P = O.init_params([8] + [H] * nh + [1], seed=11)
+    ds = synth.make_dataset(N, (), seed=12)
+    x, y = ds[0], ds[1].reshape(-1)
+    g = torch.Generator().manual_seed(5)
+    widths = [H] * nh + [H // 2]
+    per_pass = [[(torch.rand(N, w, generator=g) >= p).numpy() for w in widths] for _ in range(T)]
+    bits = hh.pack_mask_bits(per_pass).to(hh.dev())
+    pl = [p] * (nh + 1)
+    fp, xd, yd = hh.flat_params(P, H, nh).to(hh.dev()), x.to(hh.dev()).contiguous(), y.to(hh.dev()).contiguous()
+    drop = hh.dropout_struct(2, pl, bits=bits)
+    u, lv = hh.forward(lib, H, nh, fp, xd, drop, precision=2)
+    with torch.no_grad():
+        uf, lvf = O.mlp_forward(P, x, pl, [torch.from_numpy(m) for m in per_pass[0]])
+    np.testing.assert_allclose(u.cpu().numpy(), uf.numpy().reshape(-1), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lv.cpu().numpy(), lvf.numpy().reshape(-1), rtol=1e-5, atol=1e-5)
+    out = torch.empty(3, N, device=hh.dev())
+    net = hh.make_net(lib, H, nh, 2)
+    _lib.check(lib.pinn_mc_dropout(ctypes.byref(net), hh.ptr(fp), hh.ptr(xd), N, ctypes.byref(drop), T, hh.ptr(out[0]), hh.ptr(out[1]),
+                                   hh.ptr(out[2]), hh.stream()), "mc")
+    pm, au, eu = O.mc_dropout(P, x, p, T, lambda t: [torch.from_numpy(m) for m in per_pass[t]])
+    o = out.cpu().numpy()
+    np.testing.assert_allclose(o[0], np.asarray(pm).reshape(-1), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(o[1], np.asarray(au).reshape(-1), rtol=1e-4)
+    np.testing.assert_allclose(o[2], np.asarray(eu).reshape(-1), rtol=1e-3, atol=2e-6)
+    grads, loss = hh.train_grads(lib, H, nh, fp, xd, yd, drop, precision=2)
+    lo, mse, go, _, _ = O.nll_loss_and_grads(P, x, ds[1], pl, [torch.from_numpy(m) for m in per_pass[0]])
+    l = loss.cpu().numpy()
+    assert abs((l[0] + 0.01 * l[1]) / N - lo.item()) <= 2e-5 * abs(lo.item())
+    _check_grads(grads, go, H, nh, rtol=2e-4)
+
+
 def test_wide_model_surface():
     """BASELINE config 5's architecture through the reference-shaped Python surface: trains, predicts, MC-samples."""
     import pinn_amd
