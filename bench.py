@@ -253,12 +253,13 @@ def leg_config4_step(dev):
 
 def leg_config5(dev):
     """BASELINE configs[4] on one GPU: wide net [8,1024,1024,1024,1024,1] (M = 3 810 560 MAC/row), 262 144 rows:
-    training-gradient call (chain + weight gradients + reduction) and MC-dropout with T = 1024 on a 16 384-row slice,
+    training-gradient call (chain + weight gradients + reduction) and MC-dropout with T = 1024 on a 65 536-row slice
+    (512 row tiles: every CU busy; ~3 s),
     f32x6 arithmetic; MFMA fraction against 2.5 PFLOP/s / 6."""
     import ctypes
     from pinn_amd import _lib, layout
     lib = _lib.load()
-    Hw, nhw, rows, mc_rows, T = 1024, 4, 262_144, 16_384, 1024
+    Hw, nhw, rows, mc_rows, T = 1024, 4, 262_144, 65_536, 1024
     Mw = 8 * Hw + (nhw - 1) * Hw * Hw + Hw + Hw * Hw // 2 + Hw * Hw // 8 + Hw // 4
     offs, total = layout.param_offsets(8, Hw, nhw)
     g = torch.Generator().manual_seed(1)
@@ -513,18 +514,22 @@ def main():
     }
     if "mc_dropout" in head:
         out["mc_dropout"] = head["mc_dropout"]
-    # HBM bytes per launch of the chain kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
-    # in separate runs at this workload size); null when the row count or the kernel differs
-    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_summary_x6.json" if args.precision.startswith("f32x6") else "pmc_summary_v2.json")
-    if rows == 1_000_000 and os.path.exists(pmc):
+    # HBM bytes per launch of the chain kernel: NOT measured by this run -- read from the newest committed rocprofv3 PMC
+    # summary (FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes at this workload size by
+    # tools/collect_profiles.sh); null when the row count or the kernel differs
+    import glob
+    cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary_x6.json" if args.precision.startswith("f32x6") else "pmc_summary_v2.json")))
+    pmc = cand[-1] if cand else ""
+    if rows == 1_000_000 and pmc:
         try:
             key = head["roofline"]["kernel"].split("<")[0]
             k = [v for n, v in json.load(open(pmc)).items() if key in n][0]
             # gfx950 correction of the guide's HBM section: FETCH_SIZE counts 16-B/lane streaming reads at half their bytes
             out["roofline"]["traffic"] = (2.0 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024.0
-            out["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT) + ": (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024, per launch, N=1e6 " \
-                "(separate --pmc passes; the factor 2 is the guide's gfx950 correction for 16-B/lane reads and an upper bound here: the " \
-                "layer-0 activation re-reads are dword loads); by design ~3.6 GB of stash reads + 7.7 GB of stash writes, not the 36 B/row"
+            out["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT) + " (a committed profile, not this run): (2 x FETCH_SIZE + WRITE_SIZE) " \
+                "KB x 1024, per launch, N=1e6 (separate --pmc passes; the factor 2 is the guide's gfx950 correction for 16-B/lane reads and an " \
+                "upper bound here: the layer-0 activation re-reads are dword loads); by design 3.84 KB/row of stash written, 3.84 KB/row of d " \
+                "pre-activations written, the stash read back once -- see roofline_hbm_design -- not the 36 B/row the algorithm needs"
         except Exception:
             pass
 

@@ -457,9 +457,17 @@ __device__ __forceinline__ float sum_kq(float s) {
 __device__ __forceinline__ float* tiled_ptr(float* base, long long t16, int F, int lane) {
   return base + (t16 * F + 4 * (lane >> 4)) * 16 + (lane & 15);
 }
+// (stash / activation blocks are written once and read by a later phase or kernel: non-temporal, so that they do not push
+//  the weights every CU streams out of its XCD's L2 -- see PINN_STASH_ST in pinn_x6_core.h)
 __device__ __forceinline__ void store_block(float* __restrict__ p, int ib, const f32x4& v) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) p[(ib * 16 + r) * 16] = v[r];
+  for (int r = 0; r < 4; ++r) {
+#ifdef PINN_ABL_PLAINSTORE
+    p[(ib * 16 + r) * 16] = v[r];
+#else
+    __builtin_nontemporal_store(v[r], p + (ib * 16 + r) * 16);
+#endif
+  }
 }
 __device__ __forceinline__ void load_block(const float* __restrict__ p, int ib, f32x4& v) {
 #pragma unroll
