@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
             split_pair<r>(ring.read(gb & 1, 0, r), ring.read(gb & 1, 1, r), nxt);
           }
         };
-        slab_mfma<kNT>(acc, cur, pipe.cur(), lane, vchunk, dma);
+        slab_mfma<X6, kNT>(acc, cur, pipe.cur(), lane, vchunk, dma);
         pipe.advance();
         cur = nxt;
       }

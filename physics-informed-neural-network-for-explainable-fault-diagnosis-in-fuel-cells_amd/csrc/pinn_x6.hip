@@ -10,6 +10,7 @@ struct PackJobs6 {
   PackJob j[18];
   int n;
   long long copy_stride;
+  int with_f16;          // fused nets: also the two fp16 copies of the forward matrices (scheme X3)
 };
 
 static int cu_count_x() { return cu_count_cached(); }
@@ -31,6 +32,15 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(const float* __restrict__ 
     packed[j.dst + e] = h;
     packed[jobs.copy_stride + j.dst + e] = m;
     packed[2 * jobs.copy_stride + j.dst + e] = (__bf16)r2;
+    // the forward matrices again as two fp16 copies of X3::kWScale * w (scheme X3), behind the three bf16 copies:
+    // same element offsets, same K permutation
+    if (jobs.with_f16 && !j.transposed) {
+      _Float16* p16 = reinterpret_cast<_Float16*>(packed + 3 * jobs.copy_stride);
+      const float vs = v * X3::kWScale;
+      const _Float16 h16 = (_Float16)vs;
+      p16[j.dst + e] = h16;
+      p16[jobs.copy_stride + j.dst + e] = (_Float16)(vs - (float)h16);
+    }
   }
 }
 
@@ -53,6 +63,7 @@ void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st
   add(K.wv1t(), L.wv1(), H / 2, H / 4, H / 2, 1);
   jobs.n = n;
   jobs.copy_stride = K.total();
+  jobs.with_f16 = H <= 256;        // (wide nets run x6 layer kernels; that region is their activation scratch)
   hipLaunchKernelGGL(pack_x6_kernel, dim3(64, n), dim3(256), 0, st, d_params, (__bf16*)net->d_packed, jobs);
 }
 
@@ -60,33 +71,23 @@ void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st
 // wave per SIMD -- twice the CUs busy and no wave shares its SIMD's matrix core, so a tile finishes in about half the time.
 template <int H, bool MC, bool kBits, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp_x6_kernel(FwdArgs a, const __bf16* packed) {
+  using S = X3;                                   // forward passes: two fp16 parts, three products (pinn_x6_core.h)
   constexpr int kThreadsX = WAVES * 64, kTileRowsX = WAVES * 16;
   // one LDS block, small things FIRST: a ds instruction's immediate offset is 16 bits, and every per-layer bias /
   // head-weight address beyond 64 KB would need its own address register (hipcc hoists them all: spills)
   constexpr int kSmallBytes = kMaxSmall * 4, kW0Bytes = 8 * kW0Stride * 4;
   constexpr int kSlabAt = (kSmallBytes + kW0Bytes + 1023) & ~1023;
-  __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * kSlabBytes];
+  __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * S::Pipe::kSlab];
   float* small = reinterpret_cast<float*>(smem);
   float* w0t = reinterpret_cast<float*>(smem + kSmallBytes);
   char* lds_w = smem + kSlabAt;
   ParamLayout L{a.H, a.nh};
   PackLayout K{a.H, a.nh};
-  {   // small parameter vectors -> LDS (all 512 threads)
-    const SmallLayout S{L.H, L.nh};
-    const int Hh = L.H, tid = threadIdx.x;
-    for (int l = 0; l < L.nh; ++l)
-      for (int i = tid; i < Hh; i += kThreadsX) small[S.b(l) + i] = a.params[L.b(l) + i];
-    for (int i = tid; i < Hh; i += kThreadsX) small[S.wp() + i] = a.params[L.wp() + i];
-    for (int i = tid; i < Hh / 2; i += kThreadsX) small[S.bv0() + i] = a.params[L.bv0() + i];
-    for (int i = tid; i < Hh / 4; i += kThreadsX) { small[S.bv1() + i] = a.params[L.bv1() + i]; small[S.wv2() + i] = a.params[L.wv2() + i]; }
-    if (tid == 0) { small[S.bp()] = a.params[L.bp()]; small[S.bv2()] = a.params[L.bv2()]; }
-    for (int e = tid; e < Hh * 8; e += kThreadsX) w0t[(e & 7) * kW0Stride + (e >> 3)] = a.params[L.w0() + e];
-    __syncthreads();
-  }
-  Pipe6 pipe;
+  fill_small<S, kThreadsX>(small, w0t, a.params, L);
+  S::Pipe pipe;
   pipe.lds = lds_w;
-  pipe.init(packed, (unsigned)(K.total() * 2), threadIdx.x);
-  pipe.prime<clog2(H), WAVES>(first_mat<H>(K));
+  pipe.init(packed + 3 * K.total(), (unsigned)(K.total() * 2), threadIdx.x);      // the fp16 copies sit behind the three bf16 ones
+  pipe.template prime<clog2(H), WAVES>(first_mat<H>(K));
 #ifdef PINN_X6_STAMP
   for (int k = 0; k < 8; ++k) pipe.seg[k] = 0;
   pipe.last = stamp();
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp_x6_kernel(FwdArgs a
     if (!MC) {
       float u, z;
       PINN_STAMP(pipe, 3);
-      forward_pass_x6<H, kBits, false, WAVES>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z);
+      forward_pass<S, H, kBits, false, WAVES>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z);
       if (valid && lane < 16) {
         a.o0[lrow] = u;
         a.o1[lrow] = logf(softplus_f32(z) + 1e-6f);
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp_x6_kernel(FwdArgs a
         c.pass = (unsigned)(t < 0 ? 0 : t);
         float u, z;
         PINN_STAMP(pipe, 3);
-        forward_pass_x6<H, kBits, false, WAVES>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z);
+        forward_pass<S, H, kBits, false, WAVES>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z);
         if (t < 0) {
           u_eval = u;
         } else {

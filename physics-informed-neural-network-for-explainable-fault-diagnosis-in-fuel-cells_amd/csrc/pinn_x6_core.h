@@ -44,13 +44,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 constexpr int kThreadsX = 512;       // 8 waves
 constexpr int kTileRowsX = 128;      // rows per workgroup tile
-constexpr int kSlabBytes = 49152;    // 3 copies x 256 rows x 64 B
+constexpr int kCopyLds = 16384;      // one copy of a slab in LDS: <= 256 rows x 64 B
+constexpr int kSlabBytes = 3 * kCopyLds;    // x6: 3 copies (hi, mid, lo)
 
 // packed buffer: three copies (hi, mid, lo) of the bf16 layout of pinn_bf16_core.h (PackLayout), back to back.
 // One matrix of it, as the weight stream sees it (wave-uniform; the row stride is a template argument of the users):
 struct Mat {
-  unsigned off;      // bf16-element offset of (row 0, column 0) inside one copy
-  int nrb_log;       // log2 of (output rows / 16): 16-row blocks per copy; a slab has 3 << nrb_log 1-KB pieces
+  unsigned off;      // 16-bit-element offset of (row 0, column 0) inside one copy
+  int nrb_log;       // log2 of (output rows / 16): 16-row blocks per copy; a slab has kCopies << nrb_log 1-KB pieces
+  int kp_log = 0;    // log2 of the row stride: read only where the user's KP_LOG template argument is -1 (run-time choice of matrix)
 };
 constexpr int clog2(int v) { return v <= 1 ? 0 : 1 + clog2(v >> 1); }
 
@@ -101,13 +103,15 @@ __device__ __forceinline__ unsigned long long stamp() {
 // involution, the reader applies the same one).  A CU's vector-memory path takes 64 B/clk: issued as one burst
 // after the barrier, the 48 pieces of a slab stall all eight waves at issue for ~1000 cycles, so each wave issues
 // its pieces one at a time between the MFMAs of its multiply phase (slab_mfma), where the issue slot is free.
-struct Pipe6 {
+template <int NCOPY>
+struct PipeT {
+  static constexpr int kSlab = NCOPY * kCopyLds;      // bytes of one slab: NCOPY copies (x6: 3 bf16 parts; x3: 2 fp16 parts)
 #ifdef PINN_X6_STAMP
   unsigned long long seg[8], last;
 #endif
   __amdgpu_buffer_rsrc_t rsrc;   // the packed weights as a raw buffer: copy 0 at byte 0, copies 1, 2 at +copy_bytes
   unsigned copy_bytes;
-  char* lds;                 // 2 x kSlabBytes
+  char* lds;                 // 2 x kSlab
   int par, wave;             // buffer holding the current slab; wave index (uniform)
   unsigned lane_row2, lane_kq8;  // 2 * (lane >> 2), 16 B * ((lane & 3) ^ swz(lane >> 2))
 
@@ -127,13 +131,14 @@ struct Pipe6 {
   template <int KP_LOG, int WAVES = 8>
   __device__ __forceinline__ void piece(const Mat& m, int g, int j, int buf) {
     int p = wave + WAVES * j;
-    const int n = 3 << m.nrb_log;
+    const int n = NCOPY << m.nrb_log;
     p = p < n ? p : p - n;
     asm volatile("" : "+s"(p));   // or hipcc precomputes every piece's offset outside the row loop (register pressure)
-    const unsigned voff = (lane_row2 << KP_LOG) + lane_kq8;                // bytes, per lane
+    const int kp = KP_LOG >= 0 ? KP_LOG : m.kp_log;
+    const unsigned voff = (lane_row2 << kp) + lane_kq8;                    // bytes, per lane
     const int copy = p >> m.nrb_log, rb = p & ((1 << m.nrb_log) - 1);
-    const unsigned soff = (unsigned)copy * copy_bytes + 2u * (m.off + 32u * (unsigned)g + ((unsigned)(rb * 16) << KP_LOG));
-    char* dst = lds + buf * kSlabBytes + copy * (kSlabBytes / 3) + rb * 1024;
+    const unsigned soff = (unsigned)copy * copy_bytes + 2u * (m.off + 32u * (unsigned)g + ((unsigned)(rb * 16) << kp));
+    char* dst = lds + buf * kSlab + copy * kCopyLds + rb * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, voff, soff, 0, 0);
   }
   // The same for a matrix whose shape is a compile-time constant with at least WAVES 16-row blocks per copy (NRB_LOG =
@@ -144,12 +149,12 @@ struct Pipe6 {
   template <int KP_LOG, int WAVES, int NRB_LOG, int J>
   __device__ __forceinline__ void piece_s(unsigned mbase, int g, int buf) {
     constexpr int q = WAVES * J, copy = q >> NRB_LOG, rb0 = q & ((1 << NRB_LOG) - 1);
-    static_assert(WAVES <= (1 << NRB_LOG) && copy < 3, "piece_s: shape not separable");
+    static_assert(WAVES <= (1 << NRB_LOG) && copy < NCOPY, "piece_s: shape not separable");
     mbase = __builtin_amdgcn_readfirstlane(mbase);     // (wave-uniform by construction; hipcc does not always see it)
     asm volatile("" : "+s"(mbase));   // (or every piece's offset is precomputed outside the row loop: register pressure)
     const unsigned voff = (lane_row2 << KP_LOG) + lane_kq8;
     const unsigned soff = mbase + (unsigned)copy * copy_bytes + 64u * (unsigned)g + ((unsigned)(rb0 * 32) << KP_LOG);
-    char* dst = lds + buf * kSlabBytes + wave * 1024 + copy * (kSlabBytes / 3) + rb0 * 1024;
+    char* dst = lds + buf * kSlab + wave * 1024 + copy * kCopyLds + rb0 * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, voff, soff, 0, 0);
   }
   // slab 0 of the sequence
@@ -157,11 +162,11 @@ struct Pipe6 {
   __device__ __forceinline__ void prime(const Mat& first) {
     par = 0;
 #pragma unroll
-    for (int j = 0; j < 48 / WAVES; ++j)
-      if (WAVES * j < (3 << first.nrb_log)) piece<KP_LOG, WAVES>(first, 0, j, 0);
+    for (int j = 0; j < 16 * NCOPY / WAVES; ++j)
+      if (WAVES * j < (NCOPY << first.nrb_log)) piece<KP_LOG, WAVES>(first, 0, j, 0);
     __syncthreads();           // (drains the DMA: vmcnt(0) + barrier)
   }
-  __device__ __forceinline__ const char* cur() const { return lds + par * kSlabBytes; }
+  __device__ __forceinline__ const char* cur() const { return lds + par * kSlab; }
   // end of a slab step: past the barrier every wave is done reading the current slab and the next one is complete.
   // kYoung = vector-memory operations this wave has issued AFTER its last LDS-DMA of the step (the training kernels'
   // stash stores, batched behind the step's last MFMA): vmcnt counts in issue order, so waiting for all but the
@@ -179,6 +184,7 @@ struct Pipe6 {
     par ^= 1;
   }
 };
+using Pipe6 = PipeT<3>;
 
 // three bf16 fragments of the 8 fp32 values a lane holds in one 32-group: v = hi + mid + lo (exact)
 // K order inside a 32-group for the x6 kernels: B-fragment element jj = 2 r + b of lane group kq is feature
@@ -227,7 +233,7 @@ __device__ __forceinline__ bf16x8 lds_read_b128(unsigned addr) {
 }
 template <int MT>
 __device__ __forceinline__ void load_a3(AFrag3& a, unsigned addr) {
-  constexpr int kCopy = kSlabBytes / 3;
+  constexpr int kCopy = kCopyLds;
   a.h = lds_read_b128<MT * 1024>(addr);
   a.m = lds_read_b128<kCopy + MT * 1024>(addr);
   a.l = lds_read_b128<2 * kCopy + MT * 1024>(addr);
@@ -247,44 +253,117 @@ __device__ __forceinline__ void mfma6(f32x4& acc, const AFrag3& a, const Frag3& 
   c = PINN_MFMA_BF16(a.h, bh, c);
   acc = c;
 }
+// ---------------------------------------------------------------------------------------
+// x3: TWO fp16 parts, three products (hi.hi + hi.lo + lo.hi) -- the forward passes.
+// fp16 has 11 significand bits: x = hi + lo to 2^-22 |x| when lo is a normal fp16, and the dropped lo.lo term is 2^-22 of
+// the product: a dot product of 256 such terms is as accurate as torch's fp32 matmul (measured rel. rms 2.5e-7 vs 2.6e-7
+// against float64; x6: 8e-8; two bf16 parts: 4e-6), because the fp32 accumulation of the MFMA is then the larger error.
+// fp16's narrow exponent is met with exact power-of-two scales: activations x 8 (|h| <= 1.67 / (1 - p)), weights x 64
+// (a weight would have to exceed 1023 to overflow), so lo is a normal fp16 wherever it matters (|h| >= 2^-6,
+// |w| >= 2^-9; below that the error is an ABSOLUTE 2^-28 / 2^-31 -- fp16 MFMA honours subnormal operands, checked on
+// gfx950) and the accumulators carry 512 x the pre-activation: biases are pre-scaled in LDS and the factor leaves in
+// the constant of the tanh's exp2.  Gradients (1e-9 .. 1e6 with the 1/N of the loss) do not fit fp16: the backward pass
+// and the weight gradients stay x6.  Half the MFMAs, 2/3 of the LDS reads and weight DMA of the x6 forward; the chip is
+// power-bound in these kernels, so fewer matrix instructions is what buys time.
+// ---------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define PINN_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+struct Frag2 {
+  u32x4 hi, lo;
+};
+template <int R>
+__device__ __forceinline__ void split_pair2(float x0, float x1, Frag2& f) {
+  const f16x2 h = {(_Float16)x0, (_Float16)x1};
+  const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
+  const f16x2 l = {(_Float16)r0, (_Float16)r1};
+  f.hi[R] = __builtin_bit_cast(unsigned, h);
+  f.lo[R] = __builtin_bit_cast(unsigned, l);
+}
+struct AFrag2 {
+  f16x8 h, l;
+};
+template <int OFF>
+__device__ __forceinline__ f16x8 lds_read_b128_f16(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return __builtin_bit_cast(f16x8, v);
+}
+
+// The two arithmetic schemes behind the slab machinery (slab_pair / slab_mfma / layer_x6 / forward_pass_x6).
+struct X6 {
+  static constexpr int kCopies = 3;                       // weight copies per slab = LDS reads per tile
+  static constexpr float kActScale = 1.0f, kAccScale = 1.0f;
+  using Frag = Frag3;
+  using AFrag = AFrag3;
+  using Pipe = PipeT<3>;
+  template <int MT> static __device__ __forceinline__ void load(AFrag& a, unsigned addr) { load_a3<MT>(a, addr); }
+  template <int N> static __device__ __forceinline__ void wait(AFrag& a) { wait_a3<N>(a); }
+  static __device__ __forceinline__ void mma(f32x4& acc, const AFrag& a, const Frag& b) { mfma6(acc, a, b); }
+  template <int R> static __device__ __forceinline__ void split(float x0, float x1, Frag& f) { split_pair<R>(x0, x1, f); }
+};
+struct X3 {
+  static constexpr int kCopies = 2;
+  static constexpr float kActScale = 8.0f, kWScale = 64.0f, kAccScale = 512.0f;
+  using Frag = Frag2;
+  using AFrag = AFrag2;
+  using Pipe = PipeT<2>;
+  template <int MT> static __device__ __forceinline__ void load(AFrag& a, unsigned addr) {
+    a.h = lds_read_b128_f16<MT * 1024>(addr);
+    a.l = lds_read_b128_f16<kCopyLds + MT * 1024>(addr);
+  }
+  template <int N> static __device__ __forceinline__ void wait(AFrag& a) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.h), "+v"(a.l) : "n"(N)); }
+  static __device__ __forceinline__ void mma(f32x4& acc, const AFrag& a, const Frag& b) {
+    f32x4 c = acc;
+    const f16x8 bh = __builtin_bit_cast(f16x8, b.hi), bl = __builtin_bit_cast(f16x8, b.lo);
+    c = PINN_MFMA_F16(a.l, bh, c);
+    c = PINN_MFMA_F16(a.h, bl, c);
+    c = PINN_MFMA_F16(a.h, bh, c);
+    acc = c;
+  }
+  template <int R> static __device__ __forceinline__ void split(float x0, float x1, Frag& f) { split_pair2<R>(x0, x1, f); }
+};
+
 // One tile pair.  vchunk(IC<c>): VALU chunk c (one per tile) of the next group's preparation; dma(IC<slot>): this
 // wave's LDS-DMA piece(s) of the next slab.  Order pinned: MFMAs of a tile, reads of the tile after next, chunk.
 // (Measured alternatives, all slower or equal: chunk free to mix with the MFMAs; sched_group_barrier 1 MFMA : 5 VALU;
 // waves 4-7 running each chunk before instead of after its tile's MFMAs; whole-phase staggering of the two waves.)
-template <int MT, int NTOUT, typename V, typename D>
-__device__ __forceinline__ void slab_pair(f32x4 (&acc)[NTOUT], const Frag3& b, unsigned addr, AFrag3& a0, AFrag3& a1, V&& vchunk, D&& dma) {
+// LDS returns in order: "at most S::kCopies reads outstanding" retires the older tile's fragments.
+template <typename S, int MT, int NTOUT, typename V, typename D>
+__device__ __forceinline__ void slab_pair(f32x4 (&acc)[NTOUT], const typename S::Frag& b, unsigned addr, typename S::AFrag& a0,
+                                          typename S::AFrag& a1, V&& vchunk, D&& dma) {
 #ifdef PINN_ABL_PRIO
   if constexpr (MT == 0) { if (PINN_ABL_PRIO_YOUNG) __builtin_amdgcn_s_setprio(1); }
   if constexpr (MT == NTOUT / 2 && NTOUT >= 4) { if (PINN_ABL_PRIO_YOUNG) __builtin_amdgcn_s_setprio(0); }
 #endif
-  wait_a3<3>(a0);                                   // a1 (issued after a0) may still be in flight
-  mfma6(acc[MT], a0, b);
+  S::template wait<S::kCopies>(a0);                 // a1 (issued after a0) may still be in flight
+  S::mma(acc[MT], a0, b);
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (MT + 2 < NTOUT) load_a3<MT + 2>(a0, addr);
+  if constexpr (MT + 2 < NTOUT) S::template load<MT + 2>(a0, addr);
   dma(IC<MT / 2>{});
   vchunk(IC<MT>{});
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (MT + 2 < NTOUT) wait_a3<3>(a1); else wait_a3<0>(a1);
-  mfma6(acc[MT + 1], a1, b);
+  if constexpr (MT + 2 < NTOUT) S::template wait<S::kCopies>(a1); else S::template wait<0>(a1);
+  S::mma(acc[MT + 1], a1, b);
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (MT + 3 < NTOUT) load_a3<MT + 3>(a1, addr);
+  if constexpr (MT + 3 < NTOUT) S::template load<MT + 3>(a1, addr);
   vchunk(IC<MT + 1>{});
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (MT + 2 < NTOUT) slab_pair<MT + 2, NTOUT>(acc, b, addr, a0, a1, vchunk, dma);
+  if constexpr (MT + 2 < NTOUT) slab_pair<S, MT + 2, NTOUT>(acc, b, addr, a0, a1, vchunk, dma);
 }
-// the 6 x NTOUT MFMAs of one slab: acc[mt] += A_mt (hi, mid, lo) x B (hi, mid, lo), terms of order >= 2^-24 dropped.
+// the MFMAs of one slab: acc[mt] += A_mt x B over the scheme's parts (x6: terms of order >= 2^-24 dropped).
 // Program order is pinned (sched_barrier); two tiles of A fragments in flight.
-template <int NTOUT, typename V, typename D>
-__device__ __forceinline__ void slab_mfma(f32x4 (&acc)[NTOUT], const Frag3& b, const char* slab, int lane, V&& vchunk, D&& dma) {
+template <typename S, int NTOUT, typename V, typename D>
+__device__ __forceinline__ void slab_mfma(f32x4 (&acc)[NTOUT], const typename S::Frag& b, const char* slab, int lane, V&& vchunk, D&& dma) {
   const int kq = lane >> 4, i = lane & 15;
   const char* base = slab + i * 64 + ((kq ^ swz(i)) << 4);      // rows mt*16 + i: (row >> 2) & 3 == (i >> 2) & 3
   const unsigned addr = (unsigned)(unsigned long long)(lptr_t)base;
-  AFrag3 a0, a1;
+  typename S::AFrag a0, a1;
   __builtin_amdgcn_sched_barrier(0);
-  load_a3<0>(a0, addr);
-  load_a3<1>(a1, addr);
+  S::template load<0>(a0, addr);
+  S::template load<1>(a1, addr);
   __builtin_amdgcn_sched_barrier(0);
-  slab_pair<0, NTOUT>(acc, b, addr, a0, a1, vchunk, dma);
+  slab_pair<S, 0, NTOUT>(acc, b, addr, a0, a1, vchunk, dma);
 }
 
 // input layer from LDS: acc = b0 + W0 x^T in exact fp32 (K = 8); w0t is [8][kW0Stride] (k-major, padded: conflict-free)
@@ -311,15 +390,19 @@ __device__ __forceinline__ void layer_input_lds(f32x4 (&acc)[NTOUT], const float
 // place -> Frag3) in six micro-steps: 0, 1 = Philox4x32-10 (five rounds each; even groups only: one call = 16 draws);
 // 2 .. 5 = register r = k - 2 of both blocks: tanh, dropout, 3-way split (and the predict head's dot).
 // ---------------------------------------------------------------------------------------
-struct Prep {
+struct PrepBase {
   unsigned w0, w1, w2, w3;   // Philox counter / output words: one call = sixteen 8-bit draws = a lane's share of TWO 32-groups
   unsigned keep;             // injected masks (kBits) only
-  Frag3 buf[2];      // fragments of the group in the MFMAs / of the group being prepared, alternating (static parity)
 };
+template <typename S>
+struct PrepT : PrepBase {
+  typename S::Frag buf[2];   // fragments of the group in the MFMAs / of the group being prepared, alternating (static parity)
+};
+using Prep = PrepT<X6>;
 // Rounds R0 .. R0 + 4.  The round keys are wave-uniform (seed + round * Weyl constant): they stay on the scalar unit,
 // and each counter update is one three-input XOR (v_bitop3_b32, truth table 0x96).
 template <int R0>
-__device__ __forceinline__ void philox_rounds5(Prep& s, unsigned seed_lo, unsigned seed_hi) {
+__device__ __forceinline__ void philox_rounds5(PrepBase& s, unsigned seed_lo, unsigned seed_hi) {
 #pragma unroll
   for (int r = R0; r < R0 + 5; ++r) {
     const unsigned long long p0 = (unsigned long long)0xD2511F53u * s.w0;
@@ -331,7 +414,7 @@ __device__ __forceinline__ void philox_rounds5(Prep& s, unsigned seed_lo, unsign
 }
 // draw of register r of block b of the 32-group with parity par inside its 64-feature pair: byte r of word 2 par + b
 template <int PAR, int B, int R>
-__device__ __forceinline__ bool keep_draw(const Prep& s, unsigned thr) {
+__device__ __forceinline__ bool keep_draw(const PrepBase& s, unsigned thr) {
   const unsigned w = PAR == 0 ? (B == 0 ? s.w0 : s.w1) : (B == 0 ? s.w2 : s.w3);
   return ((w >> (8 * R)) & 0xFFu) >= thr;
 }
@@ -340,12 +423,19 @@ __device__ __forceinline__ bool keep_draw(const Prep& s, unsigned thr) {
 __device__ __forceinline__ float stash_value(float h, bool kept) {
   return kept ? (h == 0.0f ? 1.17549435e-38f : h) : 0.0f;
 }
+// tanh(x / acc_scale): `pre` = 2 log2(e) / acc_scale (x3: the accumulators carry 512 x the pre-activation)
+constexpr float kTanhPre = 2.8853900817779268f;
+__device__ __forceinline__ float tanh_pre(float x, float pre) {
+  const float e = __builtin_amdgcn_exp2f(x * pre);
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
 // wp32: the predict head's 32 weights of this group (LDS) when kDot; the dot is accumulated only if dot_on.
+// pre: tanh_pre's constant for the raw values v0, v1; ld.scale is the dropout scale TIMES S::kActScale.
 // sp (training only, else nullptr): this lane's slot of the group's first feature in the activation stash.
 // FP: the 32-group's index inside its dropout layer; the even group of a pair runs the Philox call, both read it.
-template <bool kBits, bool kDot, int k, int FP>
-__device__ __forceinline__ void prep_micro(Prep& s, f32x4& v0, f32x4& v1, const DropDev& d, const RowCtx& c, const LayerDrop ld,
-                                           int layer, const float* wp32, float& up, bool dot_on, Frag3& out, float* sp = nullptr) {
+template <typename S, bool kBits, bool kDot, int k, int FP>
+__device__ __forceinline__ void prep_micro(PrepBase& s, f32x4& v0, f32x4& v1, const DropDev& d, const RowCtx& c, const LayerDrop ld, float pre,
+                                           int layer, const float* wp32, float& up, bool dot_on, typename S::Frag& out, float* sp = nullptr) {
   constexpr int fp = FP, par = FP & 1;
   if constexpr (k == 0) {
     if (kBits) {
@@ -365,12 +455,16 @@ __device__ __forceinline__ void prep_micro(Prep& s, f32x4& v0, f32x4& v1, const 
     if constexpr (!kBits && par == 0) philox_rounds5<5>(s, d.seed_lo, d.seed_hi);
   } else if constexpr (k < 6) {
     constexpr int r = k - 2;
-    const float a0 = tanh_f32(v0[r]), a1 = tanh_f32(v1[r]);
+    const float a0 = tanh_pre(v0[r], pre), a1 = tanh_pre(v1[r], pre);
     const bool k0 = kBits ? ((s.keep >> r) & 1u) != 0 : keep_draw<par, 0, r>(s, ld.thr);
     const bool k1 = kBits ? ((s.keep >> (4 + r)) & 1u) != 0 : keep_draw<par, 1, r>(s, ld.thr);
-    const float h0 = k0 ? a0 * ld.scale : 0.0f;
-    const float h1 = k1 ? a1 * ld.scale : 0.0f;
-    split_pair<r>(h0, h1, out);
+    const float hs0 = k0 ? a0 * ld.scale : 0.0f;          // the matrix operand: S::kActScale x the activation
+    const float hs1 = k1 ? a1 * ld.scale : 0.0f;
+    S::template split<r>(hs0, hs1, out);
+    float h0 = hs0, h1 = hs1;                              // the activation itself (stash, predict head)
+    if constexpr (S::kActScale != 1.0f) {
+      if (sp || kDot) { h0 = hs0 * (1.0f / S::kActScale); h1 = hs1 * (1.0f / S::kActScale); }
+    }
     // training: the registers keep the value the stash will hold (stored by micro-step 6, behind the step's last DMA)
     v0[r] = sp ? stash_value(h0, k0) : h0;
     v1[r] = sp ? stash_value(h1, k1) : h1;
@@ -401,24 +495,24 @@ __device__ __forceinline__ void prep_micro(Prep& s, f32x4& v0, f32x4& v1, const 
 // whose raw values are this layer's acc[0], acc[1] -- final once the last slab's first tile pair is through, so
 // those steps sit in slots >= 1.  KPM / KPN: log2 row stride of this / the next matrix; NPM / NPN: (an upper bound
 // of) their 1-KB pieces per slab.
-template <int P, int NG, int NTOUT, int KPM, int KPN, int NPM, int NPN, bool kHasOut, int WAVES = 8, int kStIn = 0, int kStOut = 0, int NRBM = -1,
-          typename FI, typename FO>
-__device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], Pipe6& pipe, const Mat& mine, const Mat& next, int lane, Prep& st,
+template <typename S, int P, int NG, int NTOUT, int KPM, int KPN, int NPM, int NPN, bool kHasOut, int WAVES = 8, int kStIn = 0, int kStOut = 0,
+          int NRBM = -1, typename FI, typename FO>
+__device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], typename S::Pipe& pipe, const Mat& mine, const Mat& next, int lane, PrepT<S>& st,
                                          FI&& prep_in, FO&& prep_out, bool out_on = true) {
-  constexpr int kSlots = NTOUT / 2, kPerDma = (48 / WAVES + kSlots - 1) / kSlots;      // <= 48 / WAVES pieces per wave and slab
+  constexpr int kSlots = NTOUT / 2, kPerDma = (16 * S::kCopies / WAVES + kSlots - 1) / kSlots;      // <= 16 kCopies / WAVES pieces per wave and slab
   // VALU chunks: one per tile (NTOUT per slab).  The six micro-steps of the next group go to chunks
   // kFirst + k * (NTOUT - kFirst) / 6; acc[0], acc[1] (the next layer's group 0) are final from chunk 2 on.
   // Micro-step 6 (training: the group's kStIn / kStOut stash stores) is the last thing before the barrier.
   constexpr int kFirst = kHasOut ? 2 : 0, kAvail = NTOUT - kFirst;
   static_assert(kAvail >= 1, "no chunk left for the next layer's group 0");
   // NRBM >= 0: this matrix has the static shape 16 << NRBM rows x (32 NG): the cheap piece addressing (Pipe6::piece_s)
-  static_assert(NRBM < 0 || NPM == (3 << NRBM), "NRBM does not match the piece count");
+  static_assert(NRBM < 0 || NPM == (S::kCopies << NRBM), "NRBM does not match the piece count");
 #ifdef PINN_ABL_GENERIC_PIECE
   constexpr int kNrbm = -1;
 #else
   constexpr int kNrbm = NRBM;
 #endif
-  const unsigned mine_base = kNrbm >= 0 ? pipe.wave_base<KPM>(mine) : 0u;
+  const unsigned mine_base = kNrbm >= 0 ? pipe.template wave_base<KPM>(mine) : 0u;
   static_for<NG>([&](auto gc) {
     constexpr int g = decltype(gc)::value;
     // the next slab: K-group g + 1 of this matrix, or K-group 0 of the next one
@@ -428,8 +522,8 @@ __device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], Pipe6& pipe, const
       // CU's 64-B/clk vector-memory path sees one or two pieces per slot instead of eight at once
       if constexpr (NTOUT == 16 && WAVES == 8) {
         const int j = (decltype(slotc)::value - pipe.wave) & 7;
-        if constexpr (g + 1 < NG) { if (WAVES * j < NPM) pipe.piece<KPM, WAVES>(mine, g + 1, j, pipe.par ^ 1); }
-        else { if (WAVES * j < NPN) pipe.piece<KPN, WAVES>(next, 0, j, pipe.par ^ 1); }
+        if constexpr (g + 1 < NG) { if (WAVES * j < NPM) pipe.template piece<KPM, WAVES>(mine, g + 1, j, pipe.par ^ 1); }
+        else { if (WAVES * j < NPN) pipe.template piece<KPN, WAVES>(next, 0, j, pipe.par ^ 1); }
         return;
       }
 #endif
@@ -437,11 +531,11 @@ __device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], Pipe6& pipe, const
         constexpr int j = decltype(slotc)::value * kPerDma + decltype(qc)::value;
         if constexpr (g + 1 < NG) {
           if constexpr (WAVES * j < NPM) {
-            if constexpr (kNrbm >= 0) pipe.piece_s<KPM, WAVES, kNrbm, j>(mine_base, g + 1, pipe.par ^ 1);
-            else pipe.piece<KPM, WAVES>(mine, g + 1, j, pipe.par ^ 1);
+            if constexpr (kNrbm >= 0) pipe.template piece_s<KPM, WAVES, kNrbm, j>(mine_base, g + 1, pipe.par ^ 1);
+            else pipe.template piece<KPM, WAVES>(mine, g + 1, j, pipe.par ^ 1);
           }
         } else {
-          if constexpr (WAVES * j < NPN) pipe.piece<KPN, WAVES>(next, 0, j, pipe.par ^ 1);
+          if constexpr (WAVES * j < NPN) pipe.template piece<KPN, WAVES>(next, 0, j, pipe.par ^ 1);
         }
       });
     };
@@ -456,14 +550,30 @@ __device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], Pipe6& pipe, const
         }
       });
     };
-    slab_mfma<NTOUT>(acc, st.buf[(P + g) & 1], pipe.cur(), lane, vchunk, dma);
+    slab_mfma<S, NTOUT>(acc, st.buf[(P + g) & 1], pipe.cur(), lane, vchunk, dma);
     PINN_STAMP(pipe, (NTOUT == 16 ? 0 : NTOUT == 8 ? 1 : 2));      // step body; then (below) 4 + type = wait + barrier
     // (out_on: wave-uniform; false when prep_out issues nothing -- the count must never exceed the stores really issued)
-    if constexpr (g + 1 < NG) pipe.advance<kStIn>();
-    else if constexpr (kHasOut && kStOut > 0) { if (out_on) pipe.advance<kStOut>(); else pipe.advance<0>(); }
-    else pipe.advance<0>();
+    if constexpr (g + 1 < NG) pipe.template advance<kStIn>();
+    else if constexpr (kHasOut && kStOut > 0) { if (out_on) pipe.template advance<kStOut>(); else pipe.template advance<0>(); }
+    else pipe.template advance<0>();
     PINN_STAMP(pipe, 4 + (NTOUT == 16 ? 0 : NTOUT == 8 ? 1 : 2));
   });
+}
+
+// small parameter vectors -> LDS (all threads).  The biases of the matrix layers carry the accumulator scale of scheme S.
+template <typename S, int kThreads>
+__device__ __forceinline__ void fill_small(float* small, float* w0t, const float* __restrict__ params, const ParamLayout& L) {
+  const SmallLayout SL{L.H, L.nh};
+  const int Hh = L.H, tid = threadIdx.x;
+  for (int i = tid; i < Hh; i += kThreads) small[SL.b(0) + i] = params[L.b(0) + i];
+  for (int l = 1; l < L.nh; ++l)
+    for (int i = tid; i < Hh; i += kThreads) small[SL.b(l) + i] = params[L.b(l) + i] * S::kAccScale;
+  for (int i = tid; i < Hh; i += kThreads) small[SL.wp() + i] = params[L.wp() + i];
+  for (int i = tid; i < Hh / 2; i += kThreads) small[SL.bv0() + i] = params[L.bv0() + i] * S::kAccScale;
+  for (int i = tid; i < Hh / 4; i += kThreads) { small[SL.bv1() + i] = params[L.bv1() + i] * S::kAccScale; small[SL.wv2() + i] = params[L.wv2() + i]; }
+  if (tid == 0) { small[SL.bp()] = params[L.bp()]; small[SL.bv2()] = params[L.bv2()]; }
+  for (int e = tid; e < Hh * 8; e += kThreads) w0t[(e & 7) * kW0Stride + (e >> 3)] = params[L.w0() + e];
+  __syncthreads();
 }
 
 // first matrix of the forward slab sequence (the pass after the last one wraps around to it); its row stride is H
@@ -485,103 +595,103 @@ struct StashX {
   }
 };
 
-// One forward pass for this wave's 16 rows (x6 matrix math).  Returns (u, z); TRAIN: activations go to the stash,
-// v2 = the tanh'ed last variance block(s), and the weight stream continues with the backward pass's first matrix.
-template <int H, bool kBits, bool TRAIN = false, int WAVES = 8>
-__device__ __forceinline__ void forward_pass_x6(const float* w0t, const float* smallp, const ParamLayout& L, Pipe6& pipe,
-                                                const DropDev& d, const RowCtx& c, const f32x4& xa, const f32x4& xb, float& u, float& z,
-                                                const StashX* sx = nullptr, f32x4* v2_out = nullptr) {
-  constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32;
+// One forward pass for this wave's 16 rows in arithmetic scheme S (X3: the kernels' forward passes; X6 kept for
+// measurement).  Returns (u, z); TRAIN: the activations go to the stash (v2 = the tanh'ed last variance blocks too).  The
+// weight stream arrives and leaves positioned on the forward sequence's first matrix.  `smallp` holds the biases of the
+// matrix layers (b_1.., bv_0, bv_1) TIMES S::kAccScale (the kernels scale them when they fill the LDS), b_0 and the head
+// vectors as they are.
+template <typename S, int H, bool kBits, bool TRAIN = false, int WAVES = 8>
+__device__ __forceinline__ void forward_pass(const float* w0t, const float* smallp, const ParamLayout& L, typename S::Pipe& pipe,
+                                             const DropDev& d, const RowCtx& c, const f32x4& xa, const f32x4& xb, float& u, float& z,
+                                             const StashX* sx = nullptr) {
+  constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32, NC = S::kCopies;
   constexpr int kSt = TRAIN ? 8 : 0;      // stash stores per prepared group (behind the step's last DMA)
+  using Frag = typename S::Frag;
   const int lane = c.lane, kq = c.kq;
-  const SmallLayout S{L.H, L.nh};
+  const SmallLayout SL{L.H, L.nh};
   const PackLayout K{L.H, L.nh};
   constexpr int KPW = clog2(H), KPV1 = clog2((H / 2 + 63) & ~63);          // row strides: [H][H], [H/2][H]; [H/4][H/2]
   const Mat m_v0{(unsigned)K.wv0(), clog2(H / 32)}, m_v1{(unsigned)K.wv1(), clog2(H / 64)};
-  const float* wp = smallp + S.wp();
+  const float* wp = smallp + SL.wp();
   const int ll = L.nh - 1;
+  constexpr float kPre0 = kTanhPre, kPreS = kTanhPre / S::kAccScale;     // tanh of an unscaled / a scaled accumulator
+  auto drop_of = [&](int layer) { LayerDrop ld = layer_drop(d, c.mode, layer); ld.scale *= S::kActScale; return ld; };
   float up = 0.0f;
-  Prep st;
+  PrepT<S> st;
   f32x4 h[NT];
-  layer_input_lds<NT>(h, w0t, smallp + S.b(0), xa, xb, lane);      // 8 -> H in exact fp32 (K = 8)
+  layer_input_lds<NT>(h, w0t, smallp + SL.b(0), xa, xb, lane);      // 8 -> H in exact fp32 (K = 8)
   {   // group 0 of the first matrix layer's input: nothing to hide it under
-    const LayerDrop ld0 = layer_drop(d, c.mode, 0);
+    const LayerDrop ld0 = drop_of(0);
     float* sp = TRAIN ? sx->act(0, H, lane) : nullptr;
-    static_for<7>([&](auto kc) { prep_micro<kBits, true, decltype(kc)::value, 0>(st, h[0], h[1], d, c, ld0, 0, wp, up, ll == 0, st.buf[0], sp); });
+    static_for<7>([&](auto kc) { prep_micro<S, kBits, true, decltype(kc)::value, 0>(st, h[0], h[1], d, c, ld0, kPre0, 0, wp, up, ll == 0, st.buf[0], sp); });
   }
 #pragma unroll 1
   for (int l = 1; l < L.nh; ++l) {
     f32x4 acc[NT];
-    bias_blocks<NT>(acc, smallp + S.b(l), kq);
-    const LayerDrop ld_in = layer_drop(d, c.mode, l - 1), ld_out = layer_drop(d, c.mode, l);
+    bias_blocks<NT>(acc, smallp + SL.b(l), kq);
+    const LayerDrop ld_in = drop_of(l - 1), ld_out = drop_of(l);
+    const float pre_in = l == 1 ? kPre0 : kPreS;                    // layer 0's output comes from the exact-fp32 input layer
     const bool last = l == ll;
     const Mat mine{(unsigned)K.w(l), clog2(H / 16)}, next = last ? m_v0 : Mat{(unsigned)K.w(l + 1), clog2(H / 16)};
     float* sp_in = TRAIN ? sx->act(l - 1, H, lane) : nullptr;
     float* sp_out = TRAIN ? sx->act(l, H, lane) : nullptr;
     static_assert(NP % 2 == 0 && (NP / 2) % 2 == 0, "the forward layers keep the fragment buffer parity");
-    layer_x6<0, NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true, WAVES, kSt, kSt, clog2(H / 16)>(
+    layer_x6<S, 0, NP, NT, KPW, KPW, NC * H / 16, NC * H / 16, true, WAVES, kSt, kSt, clog2(H / 16)>(
         acc, pipe, mine, next, lane, st,
-        [&](auto gc, auto kc, Frag3& out) {
+        [&](auto gc, auto kc, Frag& out) {
           constexpr int g = decltype(gc)::value;
-          prep_micro<kBits, false, decltype(kc)::value, g>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, l - 1, wp, up, false, out,
-                                                        TRAIN ? sp_in + 32 * g * 16 : nullptr);
+          prep_micro<S, kBits, false, decltype(kc)::value, g>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, pre_in, l - 1, wp, up, false, out,
+                                                             TRAIN ? sp_in + 32 * g * 16 : nullptr);
         },
-        [&](auto kc, Frag3& out) {
-          prep_micro<kBits, true, decltype(kc)::value, 0>(st, acc[0], acc[1], d, c, ld_out, l, wp, up, last, out, sp_out);
+        [&](auto kc, Frag& out) {
+          prep_micro<S, kBits, true, decltype(kc)::value, 0>(st, acc[0], acc[1], d, c, ld_out, kPreS, l, wp, up, last, out, sp_out);
         });
 #pragma unroll
     for (int t = 0; t < NT; ++t) h[t] = acc[t];
   }
   // variance head, first layer: its input is the last hidden layer (group 0 is prepared already); predict head on the fly
   f32x4 v1[NT2];
-  bias_blocks<NT2>(v1, smallp + S.bv0(), kq);
+  bias_blocks<NT2>(v1, smallp + SL.bv0(), kq);
   {
-    const LayerDrop ld_in = layer_drop(d, c.mode, ll), ld_out = layer_drop(d, c.mode, L.nh);
+    const LayerDrop ld_in = drop_of(ll), ld_out = drop_of(L.nh);
+    const float pre_in = ll == 0 ? kPre0 : kPreS;
     float* sp_in = TRAIN ? sx->act(ll, H, lane) : nullptr;
     float* sp_out = TRAIN ? tiled_ptr(sx->v1, sx->t16, H / 2, lane) : nullptr;
-    layer_x6<0, NP, NT2, KPW, KPV1, 3 * H / 32, 3 * H / 64, true, WAVES, kSt, kSt, (WAVES <= H / 32 ? clog2(H / 32) : -1)>(
+    layer_x6<S, 0, NP, NT2, KPW, KPV1, NC * H / 32, NC * H / 64, true, WAVES, kSt, kSt, (WAVES <= H / 32 ? clog2(H / 32) : -1)>(
         v1, pipe, m_v0, m_v1, lane, st,
-        [&](auto gc, auto kc, Frag3& out) {
+        [&](auto gc, auto kc, Frag& out) {
           constexpr int g = decltype(gc)::value;
-          prep_micro<kBits, true, decltype(kc)::value, g>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, ll, wp + 32 * g, up, true, out,
-                                                       TRAIN ? sp_in + 32 * g * 16 : nullptr);
+          prep_micro<S, kBits, true, decltype(kc)::value, g>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, pre_in, ll, wp + 32 * g, up, true, out,
+                                                            TRAIN ? sp_in + 32 * g * 16 : nullptr);
         },
-        [&](auto kc, Frag3& out) {
-          prep_micro<kBits, false, decltype(kc)::value, 0>(st, v1[0], v1[1], d, c, ld_out, L.nh, wp, up, false, out, sp_out);
+        [&](auto kc, Frag& out) {
+          prep_micro<S, kBits, false, decltype(kc)::value, 0>(st, v1[0], v1[1], d, c, ld_out, kPreS, L.nh, wp, up, false, out, sp_out);
         });
   }
-  u = sum_kq(up) + smallp[S.bp()];
+  u = sum_kq(up) + smallp[SL.bp()];
   f32x4 v2[NT4];
-  bias_blocks<NT4>(v2, smallp + S.bv1(), kq);
+  bias_blocks<NT4>(v2, smallp + SL.bv1(), kq);
   {
-    const LayerDrop ld_in = layer_drop(d, c.mode, L.nh);
+    const LayerDrop ld_in = drop_of(L.nh);
     float* sp_in = TRAIN ? tiled_ptr(sx->v1, sx->t16, H / 2, lane) : nullptr;
-    auto prep_in = [&](auto gc, auto kc, Frag3& out) {
+    auto prep_in = [&](auto gc, auto kc, Frag& out) {
       constexpr int g = decltype(gc)::value;
-      prep_micro<kBits, false, decltype(kc)::value, g>(st, v1[2 * g], v1[2 * g + 1], d, c, ld_in, L.nh, wp, up, false, out,
-                                                    TRAIN ? sp_in + 32 * g * 16 : nullptr);
+      prep_micro<S, kBits, false, decltype(kc)::value, g>(st, v1[2 * g], v1[2 * g + 1], d, c, ld_in, kPreS, L.nh, wp, up, false, out,
+                                                         TRAIN ? sp_in + 32 * g * 16 : nullptr);
     };
-    if constexpr (TRAIN) {
-      // the backward pass starts with Wv1^T: [H/2][H/4], row stride padded to 64
-      constexpr int KPT1 = clog2((H / 4 + 63) & ~63);
-      const Mat m_t1{(unsigned)K.wv1t(), clog2(H / 32)};
-      layer_x6<0, NP / 2, NT4, KPV1, KPT1, 3 * H / 64, 3 * H / 32, false, WAVES, kSt, 0>(v2, pipe, m_v1, m_t1, lane, st, prep_in, [&](auto, Frag3&) {});
-    } else {
-      layer_x6<0, NP / 2, NT4, KPV1, KPW, 3 * H / 64, 3 * H / 16, false, WAVES>(v2, pipe, m_v1, first_mat<H>(K), lane, st, prep_in, [&](auto, Frag3&) {});
-    }
+    layer_x6<S, 0, NP / 2, NT4, KPV1, KPW, NC * H / 64, NC * H / 16, false, WAVES, kSt, 0>(v2, pipe, m_v1, first_mat<H>(K), lane, st, prep_in,
+                                                                                          [&](auto, Frag&) {});
   }
   float zp = 0.0f;
   float* sp2 = TRAIN ? tiled_ptr(sx->v2, sx->t16, H / 4, lane) : nullptr;
 #pragma unroll
   for (int t = 0; t < NT4; ++t) {
-    activate_tanh(v2[t]);
-    zp = block_dot(v2[t], smallp + S.wv2() + t * 16, kq, zp);
-    if (TRAIN) {
-      store_block(sp2, t, v2[t]);
-      v2_out[t] = v2[t];
-    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v2[t][r] = tanh_pre(v2[t][r], kPreS);
+    zp = block_dot(v2[t], smallp + SL.wv2() + t * 16, kq, zp);
+    if (TRAIN) store_block(sp2, t, v2[t]);
   }
-  z = sum_kq(zp) + smallp[S.bv2()];
+  z = sum_kq(zp) + smallp[SL.bv2()];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -634,11 +744,11 @@ __device__ __forceinline__ void bprep_micro(Frag3& out, f32x4& d0, f32x4& d1, co
 }
 
 // Backward chain of this wave's 16 rows: d pre-activations of every layer to the stash.  du, dz = d loss / d (u, z);
-// v2 = tanh'ed last variance blocks.  The weight stream arrives positioned on Wv1^T and leaves on the forward pass's
-// first matrix.
+// the tanh'ed last variance blocks come from the stash (the forward pass is a kernel of its own).  The weight stream
+// arrives positioned on Wv1^T and leaves there (the next tile's backward pass).
 template <int H, int WAVES = 8>
 __device__ __forceinline__ void backward_pass_x6(const float* smallp, const ParamLayout& L, Pipe6& pipe, const DropDev& d, int mode,
-                                                 const StashX& sx, const StashRing& ring, int lane, float du, float dz, f32x4* v2) {
+                                                 const StashX& sx, const StashRing& ring, int lane, float du, float dz) {
   constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32;
   constexpr int NG1 = (H / 4) / 32 > 0 ? (H / 4) / 32 : 1;                 // K-groups of Wv1^T (K = H/4)
   constexpr int KPW = clog2(H), KPT0 = clog2((H / 2 + 63) & ~63), KPT1 = clog2((H / 4 + 63) & ~63);
@@ -661,7 +771,11 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
   Prep st;
   constexpr int P1 = NG1 & 1;      // fragment buffer parity after Wv1^T (its group count is odd for H = 128)
   // ---- d pre_v2 = wv2 * dz * (1 - v2^2): the B operand of Wv1^T, all in registers
+  f32x4 v2[NT4];
   {
+    const float* vp = tiled_ptr(sx.v2, sx.t16, H / 4, lane);
+#pragma unroll
+    for (int t = 0; t < NT4; ++t) load_block(vp, t, v2[t]);
     float* sp = tiled_ptr(sx.dv2, sx.t16, H / 4, lane);
 #pragma unroll
     for (int t = 0; t < NT4; ++t) {
@@ -674,7 +788,7 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     else { const f32x4 zero = {0.f, 0.f, 0.f, 0.f}; st.buf[0] = split3(v2[0], zero); }     // H = 128: K = 32 of a padded 64... one real block
   }
   const Mat m_t1{(unsigned)K.wv1t(), clog2(H / 32)}, m_t0{(unsigned)K.wv0t(), clog2(H / 16)};
-  const Mat m_first = first_mat<H>(K);
+  const Mat m_again{m_t1.off, m_t1.nrb_log, KPT1};                          // the next tile's first matrix (run-time row stride)
 
   // ---- d h_v1 = Wv1^T d pre_v2; lazily -> d pre_v1 (stash block i = its group)
   f32x4 dpv1[NT2];
@@ -683,7 +797,7 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     const LayerDrop ldv = layer_drop(d, mode, nh);
     const float scale = ldv.scale, inv_scale = 1.0f / scale;
     float* dsp = tiled_ptr(sx.dv1, sx.t16, H / 2, lane);
-    layer_x6<0, NG1, NT2, KPT1, KPT0, 3 * H / 32, 3 * H / 16, true, WAVES, 0, 8, (WAVES <= H / 32 ? clog2(H / 32) : -1)>(
+    layer_x6<X6, 0, NG1, NT2, KPT1, KPT0, 3 * H / 32, 3 * H / 16, true, WAVES, 0, 8, (WAVES <= H / 32 ? clog2(H / 32) : -1)>(
         dpv1, pipe, m_t1, m_t0, lane, st,
         [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
@@ -711,8 +825,8 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     const float scale = ldv.scale, inv_scale = 1.0f / scale, scale_o = ldh.scale, inv_scale_o = 1.0f / scale_o;
     float* dsp = tiled_ptr(sx.dv1, sx.t16, H / 2, lane);
     float* dsp_o = sx.dact(nh - 1, H, lane);
-    const Mat next = nh > 1 ? Mat{(unsigned)K.wt(nh - 1), clog2(H / 16)} : m_first;
-    layer_x6<P1, NP / 2, NT, KPT0, KPW, 3 * H / 16, 3 * H / 16, true, WAVES, 8, 8, clog2(H / 16)>(
+    const Mat next = nh > 1 ? Mat{(unsigned)K.wt(nh - 1), clog2(H / 16), KPW} : m_again;
+    layer_x6<X6, P1, NP / 2, NT, KPT0, -1, 3 * H / 16, 3 * H / 16, true, WAVES, 8, 8, clog2(H / 16)>(
         dh, pipe, m_t0, next, lane, st,
         [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
@@ -739,8 +853,8 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     float* dsp = sx.dact(l, H, lane);
     float* dsp_o = sx.dact(l - 1, H, lane);
     const int base = NP / 2 + (nh - 1 - l) * NP;           // stash block index of this layer's group 0
-    const Mat mine{(unsigned)K.wt(l), clog2(H / 16)}, next = l > 1 ? Mat{(unsigned)K.wt(l - 1), clog2(H / 16)} : m_first;
-    layer_x6<P1, NP, NT, KPW, KPW, 3 * H / 16, 3 * H / 16, true, WAVES, 8, 8, clog2(H / 16)>(
+    const Mat mine{(unsigned)K.wt(l), clog2(H / 16)}, next = l > 1 ? Mat{(unsigned)K.wt(l - 1), clog2(H / 16), KPW} : m_again;
+    layer_x6<X6, P1, NP, NT, KPW, -1, 3 * H / 16, 3 * H / 16, true, WAVES, 8, 8, clog2(H / 16)>(
         acc, pipe, mine, next, lane, st,
         [&](auto gc, auto kc, Frag3& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;

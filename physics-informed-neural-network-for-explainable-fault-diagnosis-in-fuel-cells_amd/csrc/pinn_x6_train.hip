@@ -1,5 +1,6 @@
 // pinn_x6_train.hip -- train_dnn's forward + aleatoric_loss + backward chain (01:949-953) with fp32-accurate
-// matrix products on the bf16 matrix cores (pinn_net_t.precision = PINN_PREC_F32X6; see pinn_x6_core.h).
+// matrix products on the matrix cores (pinn_net_t.precision = PINN_PREC_F32X6; see pinn_x6_core.h): forward in
+// scheme X3 (two fp16 parts), backward in x6 (three bf16 parts).
 // Same stash layout and outputs as train_chain_kernel (pinn_train.hip): the weight-gradient and finalize
 // kernels that follow are shared.
 #include <cstdlib>
@@ -20,40 +21,32 @@ struct TrainArgsX {
   TrainBuffers b;
 };
 
+// Two kernels.  The forward half (activations stashed, aleatoric loss, d loss / d (u, z)) runs in scheme X3 -- two fp16
+// parts, three MFMAs per product: activations and weights fit fp16's range; the backward half needs bf16's range for the
+// gradients (1 / N of the loss in front, precisions up to 1e6) and runs in x6 on the transposed copies.  The seam carries
+// nothing in registers: du, dz go through their [rows] buffers (the weight-gradient kernels read them anyway), the
+// tanh'ed last variance blocks through the stash.
 // WAVES: 8 = 128-row tiles, two waves per SIMD; 4 = 64-row tiles, one wave per SIMD (small row counts, see mlp_x6_kernel)
 template <int H, bool kBits, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_chain_x6_kernel(TrainArgsX a, const __bf16* packed) {
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_fwd_x3_kernel(TrainArgsX a, const __bf16* packed) {
+  using S = X3;
   constexpr int kThreadsX = WAVES * 64, kTileRowsX = WAVES * 16;
-  constexpr int NT4 = H / 64;
-  constexpr int kSmallBytes = kMaxSmall * 4, kW0Bytes = 8 * kW0Stride * 4, kRingBytes = 8 * 2 * 2048, kRedBytes = 8 * kLossTermsX * 8;
-  constexpr int kSlabAt = (kSmallBytes + kW0Bytes + kRedBytes + kRingBytes + 1023) & ~1023;
-  __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * kSlabBytes];
+  constexpr int kSmallBytes = kMaxSmall * 4, kW0Bytes = 8 * kW0Stride * 4, kRedBytes = 8 * kLossTermsX * 8;
+  constexpr int kSlabAt = (kSmallBytes + kW0Bytes + kRedBytes + 1023) & ~1023;
+  __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * S::Pipe::kSlab];
   float* small = reinterpret_cast<float*>(smem);
   float* w0t = reinterpret_cast<float*>(smem + kSmallBytes);
   double (*red)[kLossTermsX] = reinterpret_cast<double (*)[kLossTermsX]>(smem + kSmallBytes + kW0Bytes);
-  char* ring_lds = smem + kSmallBytes + kW0Bytes + kRedBytes;
   char* lds_w = smem + kSlabAt;
   ParamLayout L{a.H, a.nh};
   PackLayout K{a.H, a.nh};
-  {   // small parameter vectors and W0^T -> LDS
-    const SmallLayout S{L.H, L.nh};
-    const int Hh = L.H, tid = threadIdx.x;
-    for (int l = 0; l < L.nh; ++l)
-      for (int i = tid; i < Hh; i += kThreadsX) small[S.b(l) + i] = a.params[L.b(l) + i];
-    for (int i = tid; i < Hh; i += kThreadsX) small[S.wp() + i] = a.params[L.wp() + i];
-    for (int i = tid; i < Hh / 2; i += kThreadsX) small[S.bv0() + i] = a.params[L.bv0() + i];
-    for (int i = tid; i < Hh / 4; i += kThreadsX) { small[S.bv1() + i] = a.params[L.bv1() + i]; small[S.wv2() + i] = a.params[L.wv2() + i]; }
-    if (tid == 0) { small[S.bp()] = a.params[L.bp()]; small[S.bv2()] = a.params[L.bv2()]; }
-    for (int e = tid; e < Hh * 8; e += kThreadsX) w0t[(e & 7) * kW0Stride + (e >> 3)] = a.params[L.w0() + e];
-    __syncthreads();
-  }
-  Pipe6 pipe;
+  fill_small<S, kThreadsX>(small, w0t, a.params, L);
+  S::Pipe pipe;
   pipe.lds = lds_w;
-  pipe.init(packed, (unsigned)(K.total() * 2), threadIdx.x);
-  pipe.prime<clog2(H), WAVES>(first_mat<H>(K));
+  pipe.init(packed + 3 * K.total(), (unsigned)(K.total() * 2), threadIdx.x);      // the fp16 copies, behind the three bf16 ones
+  pipe.template prime<clog2(H), WAVES>(first_mat<H>(K));
 
   const int lane = threadIdx.x & 63, wave = pipe.wave, kq = lane >> 4;
-  const StashRing ring{ring_lds + wave * 4096, lane};
   const float inv_n = (float)(1.0 / (double)a.n_global);
   float s_nll = 0.f, s_abs = 0.f, s_mse = 0.f, s_du = 0.f, s_dz = 0.f;
 
@@ -72,8 +65,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_chain_x6_kernel(T
 
     // ------------------------------------------------------------------ forward (activations stashed)
     float u, z;
-    f32x4 v2[NT4];
-    forward_pass_x6<H, kBits, true, WAVES>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z, &sx, v2);
+    forward_pass<S, H, kBits, true, WAVES>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z, &sx);
 
     // ------------------------------------------------------------------ aleatoric_loss (01:916-927) and its gradient
     float du = 0.f, dz = 0.f;
@@ -100,11 +92,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_chain_x6_kernel(T
       }
       if (lane < 16) { a.b.du[t16 * 16 + lane] = du; a.b.dz[t16 * 16 + lane] = dz; }
     }
-
-    // ------------------------------------------------------------------ backward chain
-#ifndef PINN_X6_NOBWD
-    backward_pass_x6<H, WAVES>(small, L, pipe, a.drop, a.drop.mode, sx, ring, lane, du, dz, v2);
-#endif
   }
 
   // ---------------------------------------------------------------------- loss partial sums of this workgroup
@@ -122,6 +109,38 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_chain_x6_kernel(T
     if (threadIdx.x < 5)
       for (int w = 0; w < WAVES; ++w) t += red[w][threadIdx.x];
     a.b.loss_part[(long long)blockIdx.x * kLossTermsX + threadIdx.x] = t;
+  }
+}
+
+// backward chain of every row tile: d pre-activations of all layers to the stash (x6 on the transposed copies)
+template <int H, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_bwd_x6_kernel(TrainArgsX a, const __bf16* packed) {
+  constexpr int kThreadsX = WAVES * 64, kTileRowsX = WAVES * 16;
+  constexpr int kSmallBytes = kMaxSmall * 4, kW0Bytes = 8 * kW0Stride * 4, kRingBytes = 8 * 2 * 2048;
+  constexpr int kSlabAt = (kSmallBytes + kW0Bytes + kRingBytes + 1023) & ~1023;
+  __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * kSlabBytes];
+  float* small = reinterpret_cast<float*>(smem);
+  float* w0t = reinterpret_cast<float*>(smem + kSmallBytes);                 // (filled, unused: one LDS fill routine)
+  char* ring_lds = smem + kSmallBytes + kW0Bytes;
+  char* lds_w = smem + kSlabAt;
+  ParamLayout L{a.H, a.nh};
+  PackLayout K{a.H, a.nh};
+  fill_small<X6, kThreadsX>(small, w0t, a.params, L);
+  Pipe6 pipe;
+  pipe.lds = lds_w;
+  pipe.init(packed, (unsigned)(K.total() * 2), threadIdx.x);
+  constexpr int KPT1 = clog2((H / 4 + 63) & ~63);
+  pipe.template prime<KPT1, WAVES>(Mat{(unsigned)K.wv1t(), clog2(H / 32)});   // the backward sequence starts with Wv1^T
+
+  const int lane = threadIdx.x & 63, wave = pipe.wave;
+  const StashRing ring{ring_lds + wave * 4096, lane};
+  const long long n_tiles = (a.n_rows + 127) / 128 * (128 / kTileRowsX);
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long t16 = tile * WAVES + wave;
+    const StashX sx{(float*)a.b.stash_h, (float*)a.b.stash_v1, (float*)a.b.stash_v2, (float*)a.b.dpre_h, (float*)a.b.dpre_v1, (float*)a.b.dpre_v2,
+                    a.b.t16, t16};
+    const float du = a.b.du[t16 * 16 + (lane & 15)], dz = a.b.dz[t16 * 16 + (lane & 15)];
+    backward_pass_x6<H, WAVES>(small, L, pipe, a.drop, a.drop.mode, sx, ring, lane, du, dz);
   }
 }
 
@@ -152,10 +171,20 @@ int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const fl
   *grid_out = grid;
   const __bf16* packed = (const __bf16*)net->d_packed;
   const bool bits = drop.mode == PINN_DROP_BITS;
+#ifdef PINN_X6_NOBWD
+  constexpr bool fwd_only = true;        // measurement builds: the forward kernel alone
+#else
+  constexpr bool fwd_only = false;
+#endif
 #define PINN_LAUNCH_T(HH, BB)                                                                                                   \
   do {                                                                                                                          \
-    if (small_n) hipLaunchKernelGGL((train_chain_x6_kernel<HH, BB, 4>), dim3(grid), dim3(256), 0, st, a, packed);               \
-    else hipLaunchKernelGGL((train_chain_x6_kernel<HH, BB, 8>), dim3(grid), dim3(512), 0, st, a, packed);                       \
+    if (small_n) {                                                                                                              \
+      hipLaunchKernelGGL((train_fwd_x3_kernel<HH, BB, 4>), dim3(grid), dim3(256), 0, st, a, packed);                            \
+      if (!fwd_only) hipLaunchKernelGGL((train_bwd_x6_kernel<HH, 4>), dim3(grid), dim3(256), 0, st, a, packed);                 \
+    } else {                                                                                                                    \
+      hipLaunchKernelGGL((train_fwd_x3_kernel<HH, BB, 8>), dim3(grid), dim3(512), 0, st, a, packed);                            \
+      if (!fwd_only) hipLaunchKernelGGL((train_bwd_x6_kernel<HH, 8>), dim3(grid), dim3(512), 0, st, a, packed);                 \
+    }                                                                                                                           \
   } while (0)
   if (net->hidden == 256) { if (bits) PINN_LAUNCH_T(256, true); else PINN_LAUNCH_T(256, false); }
   else { if (bits) PINN_LAUNCH_T(128, true); else PINN_LAUNCH_T(128, false); }

@@ -70,7 +70,7 @@ def test_train_grads_full_size_deterministic_and_shard_additive(lib, data, prec,
     assert scale > 0
     # fp32 sums in a different order (bf16 family: bf16-rounded stash, same tolerance relative to the largest element)
     assert float((ga + gb - g1).abs().max()) <= 2e-5 * scale, name
-    np.testing.assert_allclose((la + lb).cpu().numpy()[:3], l1.cpu().numpy()[:3], rtol=1e-9)
+    np.testing.assert_allclose((la + lb).cpu().numpy()[:3], l1.cpu().numpy()[:3], rtol=1e-7)      # (each lane adds its ~30 tiles in fp32 first)
 
 
 @pytest.mark.parametrize("prec,name", PRECS)

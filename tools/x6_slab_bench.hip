@@ -23,7 +23,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const __bf16* packed, in
   unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
     auto dma = [&](auto slotc) { constexpr int slot = decltype(slotc)::value; if (DMA && slot < 6) pipe.piece<8>(m, it & 7, slot, pipe.par ^ 1); };
-    slab_mfma<16>(acc, b, pipe.cur(), lane, [](auto) {}, dma);
+    slab_mfma<X6, 16>(acc, b, pipe.cur(), lane, [](auto) {}, dma);
     if (DMA) { __syncthreads(); pipe.par ^= 1; }
   }
   unsigned long long t1 = __builtin_readcyclecounter();
