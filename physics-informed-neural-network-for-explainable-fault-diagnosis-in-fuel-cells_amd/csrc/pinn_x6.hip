@@ -32,9 +32,9 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(const float* __restrict__ 
     packed[j.dst + e] = h;
     packed[jobs.copy_stride + j.dst + e] = m;
     packed[2 * jobs.copy_stride + j.dst + e] = (__bf16)r2;
-    // the forward matrices again as two fp16 copies of X3::kWScale * w (scheme X3), behind the three bf16 copies:
-    // same element offsets, same K permutation
-    if (jobs.with_f16 && !j.transposed) {
+    // every matrix again as two fp16 copies of X3::kWScale * w (scheme X3: forward and backward chain), behind the three
+    // bf16 copies (weight gradients): same element offsets, same K permutation
+    if (jobs.with_f16) {
       _Float16* p16 = reinterpret_cast<_Float16*>(packed + 3 * jobs.copy_stride);
       const float vs = v * X3::kWScale;
       const _Float16 h16 = (_Float16)vs;

@@ -714,46 +714,47 @@ struct StashRing {
   }
 };
 
-// micro-step k of a backward group: raw d0, d1 = d loss / d h (two 16-feature blocks) -> d pre-activation in place,
+// micro-step k of a backward group: raw d0, d1 = (acc_scale x) d loss / d h (two 16-feature blocks) -> d pre-activation in place,
 // split for the next matrix (k = 2 .. 5) and stashed for the weight-gradient kernels (dsp; k = 6).  h = post-dropout activation from
-// the stash copy in LDS: dropped <=> h == 0, a = h / scale, d pre = d h * scale * (1 - a^2).
-template <int k>
-__device__ __forceinline__ void bprep_micro(Frag3& out, f32x4& d0, f32x4& d1, const StashRing& ring, int buf, float* dsp, float scale,
-                                            float inv_scale) {
+// the stash copy in LDS: dropped <=> h == 0, a = h / drop_scale, d pre = d h * gscale * (1 - a^2) with gscale = the dropout
+// scale over the accumulator scale of the matrix that produced d0, d1.  The values in flight are the row's gradients times
+// its normalisation (scheme X3, see backward_pass); the stash gets them back in true units: x unnorm.
+template <typename S, int k>
+__device__ __forceinline__ void bprep_micro(typename S::Frag& out, f32x4& d0, f32x4& d1, const StashRing& ring, int buf, float* dsp, float gscale,
+                                            float inv_scale, float unnorm) {
   if constexpr (k >= 2 && k < 6) {
     constexpr int r = k - 2;
     const float h0 = ring.read(buf, 0, r), h1 = ring.read(buf, 1, r);
     const float a0 = h0 * inv_scale, a1 = h1 * inv_scale;
-    const float g0 = d0[r] * (scale * (1.0f - a0 * a0)), g1 = d1[r] * (scale * (1.0f - a1 * a1));
+    const float g0 = d0[r] * (gscale * (1.0f - a0 * a0)), g1 = d1[r] * (gscale * (1.0f - a1 * a1));
     const float p0 = h0 != 0.0f ? g0 : 0.0f, p1 = h1 != 0.0f ? g1 : 0.0f;
     d0[r] = p0; d1[r] = p1;
-    split_pair<r>(p0, p1, out);
-  } else if constexpr (k == 6) {      // the group's eight stores, behind the step's last DMA (Pipe6::advance<8>)
-#ifdef PINN_ABL_WIDESTORE
-    float* q = dsp - (4 * (ring.lane >> 4) * 16 + (ring.lane & 15)) + ring.lane * 8;
-    *reinterpret_cast<f32x4*>(q) = d0;
-    *reinterpret_cast<f32x4*>(q + 4) = d1;
-#else
+    S::template split<r>(p0, p1, out);
+  } else if constexpr (k == 6) {      // the group's eight stores, behind the step's last DMA (PipeT::advance<8>)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      PINN_STASH_ST(dsp + r * 16, d0[r]);
-      PINN_STASH_ST(dsp + (16 + r) * 16, d1[r]);
+      PINN_STASH_ST(dsp + r * 16, S::kActScale != 1.0f ? d0[r] * unnorm : d0[r]);
+      PINN_STASH_ST(dsp + (16 + r) * 16, S::kActScale != 1.0f ? d1[r] * unnorm : d1[r]);
     }
-#endif
   }
 }
 
-// Backward chain of this wave's 16 rows: d pre-activations of every layer to the stash.  du, dz = d loss / d (u, z);
-// the tanh'ed last variance blocks come from the stash (the forward pass is a kernel of its own).  The weight stream
-// arrives positioned on Wv1^T and leaves there (the next tile's backward pass).
-template <int H, int WAVES = 8>
-__device__ __forceinline__ void backward_pass_x6(const float* smallp, const ParamLayout& L, Pipe6& pipe, const DropDev& d, int mode,
-                                                 const StashX& sx, const StashRing& ring, int lane, float du, float dz) {
-  constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32;
+// Backward chain of this wave's 16 rows in scheme S: d pre-activations of every layer to the stash.  du, dz = d loss /
+// d (u, z); the tanh'ed last variance blocks come from the stash (the forward pass is a kernel of its own).  The weight
+// stream arrives positioned on Wv1^T and leaves there (the next tile's backward pass).
+// X3: the gradients (1 / N of the loss in front, precisions up to 1e6: 1e-9 .. 1e6) do not fit fp16 as they are -- but a
+// row is one COLUMN of every product W^T d, so it may carry its own scale: each row's (du, dz) is normalised by an exact
+// power of two to max(|du|, |dz|) in [8, 16) (`norm`), the whole chain of that row runs on normalised values (bounded by
+// the weights' row sums, far inside fp16's range), and what goes to the stash is multiplied by 1 / norm again (exact).
+template <typename S, int H, int WAVES = 8>
+__device__ __forceinline__ void backward_pass(const float* smallp, const ParamLayout& L, typename S::Pipe& pipe, const DropDev& d, int mode,
+                                              const StashX& sx, const StashRing& ring, int lane, float du, float dz) {
+  constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32, NC = S::kCopies;
   constexpr int NG1 = (H / 4) / 32 > 0 ? (H / 4) / 32 : 1;                 // K-groups of Wv1^T (K = H/4)
   constexpr int KPW = clog2(H), KPT0 = clog2((H / 2 + 63) & ~63), KPT1 = clog2((H / 4 + 63) & ~63);
+  using Frag = typename S::Frag;
   const int kq = lane >> 4;
-  const SmallLayout S{L.H, L.nh};
+  const SmallLayout SL{L.H, L.nh};
   const PackLayout K{L.H, L.nh};
   const int nh = L.nh;
   const int n_blocks = NP / 2 + (nh - 1) * NP;                             // stash blocks that feed a matrix, in order
@@ -768,7 +769,20 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
   };
   fetch_block(0);
 
-  Prep st;
+  // per-row normalisation (X3): norm = 2^(4 - e) with max(|du|, |dz|) = m 2^e, m in [0.5, 1)
+  float unnorm = 1.0f;
+  if constexpr (S::kActScale != 1.0f) {
+    int e = 0;
+    const float mx = fmaxf(fabsf(du), fabsf(dz));
+    (void)frexpf(mx, &e);
+    e = mx > 0.0f ? (e < -120 ? -120 : e) : 4;                             // (all-zero row, padding: norm = 1)
+    const float norm = ldexpf(1.0f, 4 - e);
+    unnorm = ldexpf(1.0f, e - 4);
+    du *= norm; dz *= norm;
+  }
+  constexpr float kInvW = 1.0f / (S::kAccScale / S::kActScale);            // 1 / weight scale: accumulators carry kWScale x W^T d
+
+  PrepT<S> st;
   constexpr int P1 = NG1 & 1;      // fragment buffer parity after Wv1^T (its group count is odd for H = 128)
   // ---- d pre_v2 = wv2 * dz * (1 - v2^2): the B operand of Wv1^T, all in registers
   f32x4 v2[NT4];
@@ -779,13 +793,18 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     float* sp = tiled_ptr(sx.dv2, sx.t16, H / 4, lane);
 #pragma unroll
     for (int t = 0; t < NT4; ++t) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(smallp + S.wv2() + t * 16 + 4 * kq);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(smallp + SL.wv2() + t * 16 + 4 * kq);
+      f32x4 true_units;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v2[t][r] = w[r] * dz * (1.0f - v2[t][r] * v2[t][r]);
-      store_block(sp, t, v2[t]);
+      for (int r = 0; r < 4; ++r) {
+        v2[t][r] = w[r] * dz * (1.0f - v2[t][r] * v2[t][r]);
+        true_units[r] = v2[t][r] * unnorm;
+      }
+      store_block(sp, t, true_units);
     }
-    if constexpr (NT4 >= 2) st.buf[0] = split3(v2[0], v2[1]);
-    else { const f32x4 zero = {0.f, 0.f, 0.f, 0.f}; st.buf[0] = split3(v2[0], zero); }     // H = 128: K = 32 of a padded 64... one real block
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4& second = NT4 >= 2 ? v2[NT4 >= 2 ? 1 : 0] : zero;           // H = 128: K = 32 of a padded 64, one real block
+    static_for<4>([&](auto rc) { constexpr int r = decltype(rc)::value; S::template split<r>(v2[0][r], second[r], st.buf[0]); });
   }
   const Mat m_t1{(unsigned)K.wv1t(), clog2(H / 32)}, m_t0{(unsigned)K.wv0t(), clog2(H / 16)};
   const Mat m_again{m_t1.off, m_t1.nrb_log, KPT1};                          // the next tile's first matrix (run-time row stride)
@@ -795,21 +814,21 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
   zero_blocks<NT2>(dpv1);
   {
     const LayerDrop ldv = layer_drop(d, mode, nh);
-    const float scale = ldv.scale, inv_scale = 1.0f / scale;
+    const float gscale = ldv.scale * kInvW, inv_scale = 1.0f / ldv.scale;
     float* dsp = tiled_ptr(sx.dv1, sx.t16, H / 2, lane);
-    layer_x6<X6, 0, NG1, NT2, KPT1, KPT0, 3 * H / 32, 3 * H / 16, true, WAVES, 0, 8, (WAVES <= H / 32 ? clog2(H / 32) : -1)>(
+    layer_x6<S, 0, NG1, NT2, KPT1, KPT0, NC * H / 32, NC * H / 16, true, WAVES, 0, 8, (WAVES <= H / 32 ? clog2(H / 32) : -1)>(
         dpv1, pipe, m_t1, m_t0, lane, st,
-        [&](auto gc, auto kc, Frag3& out) {
+        [&](auto gc, auto kc, Frag& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
-          if constexpr (k >= 2 && k < 6 && 2 * g + 1 < NT4) split_pair<k - 2>(v2[2 * g][k - 2], v2[2 * g + 1][k - 2], out);
+          if constexpr (k >= 2 && k < 6 && 2 * g + 1 < NT4) S::template split<k - 2>(v2[2 * g][k - 2], v2[2 * g + 1][k - 2], out);
         },
-        [&](auto kc, Frag3& out) {
+        [&](auto kc, Frag& out) {
           constexpr int k = decltype(kc)::value;
           if constexpr (k == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // block 0 was requested at the top of this pass
             fetch_block(1);
           }
-          bprep_micro<k>(out, dpv1[0], dpv1[1], ring, 0, dsp, scale, inv_scale);
+          bprep_micro<S, k>(out, dpv1[0], dpv1[1], ring, 0, dsp, gscale, inv_scale, unnorm);
         });
   }
 
@@ -817,27 +836,27 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
   f32x4 dh[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const f32x4 w = *reinterpret_cast<const f32x4*>(smallp + S.wp() + t * 16 + 4 * kq);
-    dh[t] = w * du;
+    const f32x4 w = *reinterpret_cast<const f32x4*>(smallp + SL.wp() + t * 16 + 4 * kq);
+    dh[t] = w * (du * (S::kAccScale / S::kActScale));                       // the accumulator carries the weight scale
   }
   {
     const LayerDrop ldv = layer_drop(d, mode, nh), ldh = layer_drop(d, mode, nh - 1);
-    const float scale = ldv.scale, inv_scale = 1.0f / scale, scale_o = ldh.scale, inv_scale_o = 1.0f / scale_o;
+    const float gscale = ldv.scale * kInvW, inv_scale = 1.0f / ldv.scale, gscale_o = ldh.scale * kInvW, inv_scale_o = 1.0f / ldh.scale;
     float* dsp = tiled_ptr(sx.dv1, sx.t16, H / 2, lane);
     float* dsp_o = sx.dact(nh - 1, H, lane);
     const Mat next = nh > 1 ? Mat{(unsigned)K.wt(nh - 1), clog2(H / 16), KPW} : m_again;
-    layer_x6<X6, P1, NP / 2, NT, KPT0, -1, 3 * H / 16, 3 * H / 16, true, WAVES, 8, 8, clog2(H / 16)>(
+    layer_x6<S, P1, NP / 2, NT, KPT0, -1, NC * H / 16, NC * H / 16, true, WAVES, 8, 8, clog2(H / 16)>(
         dh, pipe, m_t0, next, lane, st,
-        [&](auto gc, auto kc, Frag3& out) {
+        [&](auto gc, auto kc, Frag& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
           if constexpr (k == 0) fetch_block(g + 1);
-          bprep_micro<k>(out, dpv1[2 * g], dpv1[2 * g + 1], ring, g & 1, dsp + 32 * g * 16, scale, inv_scale);
+          bprep_micro<S, k>(out, dpv1[2 * g], dpv1[2 * g + 1], ring, g & 1, dsp + 32 * g * 16, gscale, inv_scale, unnorm);
         },
-        [&](auto kc, Frag3& out) {
+        [&](auto kc, Frag& out) {
           constexpr int k = decltype(kc)::value;
           if (nh > 1) {
             if constexpr (k == 0) fetch_block(NP / 2 + 1);
-            bprep_micro<k>(out, dh[0], dh[1], ring, (NP / 2) & 1, dsp_o, scale_o, inv_scale_o);
+            bprep_micro<S, k>(out, dh[0], dh[1], ring, (NP / 2) & 1, dsp_o, gscale_o, inv_scale_o, unnorm);
           }
         },
         nh > 1);
@@ -849,23 +868,23 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
     f32x4 acc[NT];
     zero_blocks<NT>(acc);
     const LayerDrop ld_in = layer_drop(d, mode, l), ld_out = layer_drop(d, mode, l - 1);
-    const float scale = ld_in.scale, inv_scale = 1.0f / scale, scale_o = ld_out.scale, inv_scale_o = 1.0f / scale_o;
+    const float gscale = ld_in.scale * kInvW, inv_scale = 1.0f / ld_in.scale, gscale_o = ld_out.scale * kInvW, inv_scale_o = 1.0f / ld_out.scale;
     float* dsp = sx.dact(l, H, lane);
     float* dsp_o = sx.dact(l - 1, H, lane);
     const int base = NP / 2 + (nh - 1 - l) * NP;           // stash block index of this layer's group 0
     const Mat mine{(unsigned)K.wt(l), clog2(H / 16)}, next = l > 1 ? Mat{(unsigned)K.wt(l - 1), clog2(H / 16), KPW} : m_again;
-    layer_x6<X6, P1, NP, NT, KPW, -1, 3 * H / 16, 3 * H / 16, true, WAVES, 8, 8, clog2(H / 16)>(
+    layer_x6<S, P1, NP, NT, KPW, -1, NC * H / 16, NC * H / 16, true, WAVES, 8, 8, clog2(H / 16)>(
         acc, pipe, mine, next, lane, st,
-        [&](auto gc, auto kc, Frag3& out) {
+        [&](auto gc, auto kc, Frag& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
           if constexpr (k == 0) fetch_block(base + g + 1);
-          bprep_micro<k>(out, dh[2 * g], dh[2 * g + 1], ring, (base + g) & 1, dsp + 32 * g * 16, scale, inv_scale);
+          bprep_micro<S, k>(out, dh[2 * g], dh[2 * g + 1], ring, (base + g) & 1, dsp + 32 * g * 16, gscale, inv_scale, unnorm);
         },
-        [&](auto kc, Frag3& out) {
+        [&](auto kc, Frag& out) {
           constexpr int k = decltype(kc)::value;
           if (l > 1) {
             if constexpr (k == 0) fetch_block(base + NP + 1);
-            bprep_micro<k>(out, acc[0], acc[1], ring, (base + NP) & 1, dsp_o, scale_o, inv_scale_o);
+            bprep_micro<S, k>(out, acc[0], acc[1], ring, (base + NP) & 1, dsp_o, gscale_o, inv_scale_o, unnorm);
           }
         },
         l > 1);
@@ -876,7 +895,7 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
   // ---- layer 0: d pre_0 = d h_0 * tanh' (no matrix follows: plain loads, all issued before the arithmetic)
   {
     const LayerDrop ld0 = layer_drop(d, mode, 0);
-    const float scale = ld0.scale, inv_scale = 1.0f / scale;
+    const float gscale = ld0.scale * kInvW * unnorm, inv_scale = 1.0f / ld0.scale;       // straight to true units
     const float* hp = sx.act(0, H, lane);
     float* dsp = sx.dact(0, H, lane);
     f32x4 hl[NT];
@@ -887,7 +906,7 @@ __device__ __forceinline__ void backward_pass_x6(const float* smallp, const Para
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float a0 = hl[t][r] * inv_scale;
-        const float g0 = dh[t][r] * (scale * (1.0f - a0 * a0));
+        const float g0 = dh[t][r] * (gscale * (1.0f - a0 * a0));
         dh[t][r] = hl[t][r] != 0.0f ? g0 : 0.0f;
       }
       store_block(dsp, t, dh[t]);

@@ -112,23 +112,28 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_fwd_x3_kernel(Tra
   }
 }
 
-// backward chain of every row tile: d pre-activations of all layers to the stash (x6 on the transposed copies)
-template <int H, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_bwd_x6_kernel(TrainArgsX a, const __bf16* packed) {
+// backward chain of every row tile: d pre-activations of all layers to the stash, on the transposed copies.
+// S = X6 (PINN_PREC_F32X6): three bf16 parts -- every element of a gradient keeps its own 24 significant bits, which is
+// what Adam's division by sqrt(v) needs of the small ones too (3-step golden trajectory: 0.09 of the tolerance band from
+// float64; the reference's own fp32: 0.41).  S = X3 (PINN_PREC_F32X6_G3, opt-in): two fp16 parts on per-row-normalised
+// gradients, half the MFMAs (chain 3.7 -> 3.3 ms at 1e6 rows) -- elements far below their row's largest gradient lose
+// relative precision (fp16's 5-bit exponent), 0.91 of the band: inside it against float64, 1.3 x against the reference.
+template <typename S, int H, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_bwd_kernel(TrainArgsX a, const __bf16* packed) {
   constexpr int kThreadsX = WAVES * 64, kTileRowsX = WAVES * 16;
   constexpr int kSmallBytes = kMaxSmall * 4, kW0Bytes = 8 * kW0Stride * 4, kRingBytes = 8 * 2 * 2048;
   constexpr int kSlabAt = (kSmallBytes + kW0Bytes + kRingBytes + 1023) & ~1023;
-  __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * kSlabBytes];
+  __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * S::Pipe::kSlab];
   float* small = reinterpret_cast<float*>(smem);
   float* w0t = reinterpret_cast<float*>(smem + kSmallBytes);                 // (filled, unused: one LDS fill routine)
   char* ring_lds = smem + kSmallBytes + kW0Bytes;
   char* lds_w = smem + kSlabAt;
   ParamLayout L{a.H, a.nh};
   PackLayout K{a.H, a.nh};
-  fill_small<X6, kThreadsX>(small, w0t, a.params, L);
-  Pipe6 pipe;
+  fill_small<X6, kThreadsX>(small, w0t, a.params, L);                        // (the backward pass reads head vectors only: no scaled biases)
+  typename S::Pipe pipe;
   pipe.lds = lds_w;
-  pipe.init(packed, (unsigned)(K.total() * 2), threadIdx.x);
+  pipe.init(packed + (S::kCopies == 2 ? 3 * K.total() : 0), (unsigned)(K.total() * 2), threadIdx.x);
   constexpr int KPT1 = clog2((H / 4 + 63) & ~63);
   pipe.template prime<KPT1, WAVES>(Mat{(unsigned)K.wv1t(), clog2(H / 32)});   // the backward sequence starts with Wv1^T
 
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_bwd_x6_kernel(Tra
     const StashX sx{(float*)a.b.stash_h, (float*)a.b.stash_v1, (float*)a.b.stash_v2, (float*)a.b.dpre_h, (float*)a.b.dpre_v1, (float*)a.b.dpre_v2,
                     a.b.t16, t16};
     const float du = a.b.du[t16 * 16 + (lane & 15)], dz = a.b.dz[t16 * 16 + (lane & 15)];
-    backward_pass_x6<H, WAVES>(small, L, pipe, a.drop, a.drop.mode, sx, ring, lane, du, dz);
+    backward_pass<S, H, WAVES>(small, L, pipe, a.drop, a.drop.mode, sx, ring, lane, du, dz);
   }
 }
 
@@ -171,6 +176,7 @@ int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const fl
   *grid_out = grid;
   const __bf16* packed = (const __bf16*)net->d_packed;
   const bool bits = drop.mode == PINN_DROP_BITS;
+  const bool fast_bwd = net->precision == PINN_PREC_F32X6_G3;        // opt-in: the backward chain in scheme X3 too
 #ifdef PINN_X6_NOBWD
   constexpr bool fwd_only = true;        // measurement builds: the forward kernel alone
 #else
@@ -180,10 +186,12 @@ int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const fl
   do {                                                                                                                          \
     if (small_n) {                                                                                                              \
       hipLaunchKernelGGL((train_fwd_x3_kernel<HH, BB, 4>), dim3(grid), dim3(256), 0, st, a, packed);                            \
-      if (!fwd_only) hipLaunchKernelGGL((train_bwd_x6_kernel<HH, 4>), dim3(grid), dim3(256), 0, st, a, packed);                 \
+      if (!fwd_only && fast_bwd) hipLaunchKernelGGL((train_bwd_kernel<X3, HH, 4>), dim3(grid), dim3(256), 0, st, a, packed);    \
+      else if (!fwd_only) hipLaunchKernelGGL((train_bwd_kernel<X6, HH, 4>), dim3(grid), dim3(256), 0, st, a, packed);           \
     } else {                                                                                                                    \
       hipLaunchKernelGGL((train_fwd_x3_kernel<HH, BB, 8>), dim3(grid), dim3(512), 0, st, a, packed);                            \
-      if (!fwd_only) hipLaunchKernelGGL((train_bwd_x6_kernel<HH, 8>), dim3(grid), dim3(512), 0, st, a, packed);                 \
+      if (!fwd_only && fast_bwd) hipLaunchKernelGGL((train_bwd_kernel<X3, HH, 8>), dim3(grid), dim3(512), 0, st, a, packed);    \
+      else if (!fwd_only) hipLaunchKernelGGL((train_bwd_kernel<X6, HH, 8>), dim3(grid), dim3(512), 0, st, a, packed);           \
     }                                                                                                                           \
   } while (0)
   if (net->hidden == 256) { if (bits) PINN_LAUNCH_T(256, true); else PINN_LAUNCH_T(256, false); }
