@@ -17,18 +17,22 @@ One timed "step" advances EVERY trainer of the reference once over those rows:
 value = rows of all ranks * steps / max-over-ranks wall time (weak scaling: rows per GPU fixed).
 
 Arithmetic (--precision, default f32x6 = the library default): fp32 in, fp32 out, fp32 accumulation;
-the matrix products run on the bf16 matrix cores with every operand split into three bf16 parts
-(hi + mid + lo = the fp32 value exactly) and six cross products -- the accuracy of an fp32 matmul
-(same parity tests and tolerances as the exact-fp32 kernels).  The exact-fp32 kernels
-(v_mfma_f32_*_f32) and the opt-in bf16-mixed ones are measured beside it ("exact_fp32",
-"bf16_mixed" objects) unless --only.
+the matrix products run on the 16-bit matrix cores with split operands -- forward passes: two fp16
+parts (power-of-two scaled into fp16's range), three cross products; backward chain and weight
+gradients: three bf16 parts (hi + mid + lo = the fp32 value exactly), six cross products -- the
+accuracy of an fp32 matmul (same parity tests and tolerances as the exact-fp32 kernels).  The
+exact-fp32 kernels (v_mfma_f32_*_f32), the opt-in bf16-mixed ones and the opt-in f32x6g3 variant
+(three products everywhere) are measured beside it unless --only.
 
 Extra legs reported in the same JSON line (rank 0):
    mc_dropout   : get_MC_samples-equivalent launch (1 eval + T stochastic passes, on-chip reduce)
-   roofline     : dominant kernel (forward+backward chain) timed alone with events on the launch
-                  stream; algorithmic FLOP per row = 4*M - 4096 (forward 2M + dgrad 2(M - 8H)),
-                  M = 174 400 MAC.  Peak: f32x6 executes 6 bf16 MFMA FLOP per algorithmic FLOP, so
-                  its ceiling is the dense bf16 peak / 6 = 416.7 TFLOP/s; exact fp32: 157.3 TFLOP/s.
+   roofline     : the chain (forward + loss kernel, backward kernel) timed with events on the launch
+                  stream, together and each alone; algorithmic FLOP per row = 4*M - 32 H (forward
+                  2(M - 8H) + dgrad 2(M - 8H), M = 174 400 MAC; the K = 8 input layer is exact f32).
+                  Peak = dense 16-bit MFMA peak (2.5 PFLOP/s) / matrix instructions executed per
+                  algorithmic multiply-add (forward 3, backward 6: chain 4.5 -> 555.6 TFLOP/s;
+                  MC-dropout 3 -> 833.3); "frac_if_priced_at_6_products" keeps round 1's accounting
+                  (416.7 TFLOP/s) beside it; exact fp32: 157.3 TFLOP/s.
    cpu_baseline : the CPU oracle's train_dnn step (torch CPU, autograd, torch-bernoulli masks,
                   Adam) on the host cores of this box (N = 1 only): a 1e5-row sample (median of 3)
                   AND the headline's 1e6 rows (1 warm-up on the sample + 2 timed steps), and the
@@ -58,16 +62,23 @@ STEP_FLOP_PER_ROW = 6 * M_MAC
 FWD_FLOP_PER_ROW = 2 * M_MAC
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
-# per precision: (dtype string, chain kernel name, forward kernel name, peak in algorithmic TFLOP/s)
+# Matrix instructions executed per algorithmic multiply-add ("products"), per phase -- the split-operand schemes of
+# pinn_x6_core.h: X3 = two fp16 parts, 3 products (forward passes); x6 = three bf16 parts, 6 products (backward chain,
+# weight gradients); the peak an algorithmic FLOP can be priced against is the dense 16-bit MFMA peak / products.
+# per precision: (dtype string, chain kernel name, forward kernel name, products forward, products backward, products wgrad,
+#                 peak of one executed product in TFLOP/s)
 PRECISIONS = {
-    "f32x6": ("f32 (products as 3x bf16-split operands, 6 bf16 MFMAs each, f32 accumulate: fp32-accurate)",
-              "train_chain_x6_kernel<256>", "mlp_x6_kernel<256,MC>", PEAK_BF16_MFMA_TFLOPS / 6.0),
-    "f32x6g3": ("f32 (as f32x6; weight gradients from 2 bf16 parts / 3 products)",
-                "train_chain_x6_kernel<256>", "mlp_x6_kernel<256,MC>", PEAK_BF16_MFMA_TFLOPS / 6.0),
-    "fp32": ("f32 (exact: v_mfma_f32_*_f32)", "train_chain_kernel<256>", "mlp_kernel<256,MC>", PEAK_FP32_MFMA_TFLOPS),
+    "f32x6": ("f32 (split-operand matrix products, f32 accumulate, fp32-matmul accuracy: forward 2 fp16 parts / 3 MFMAs, "
+              "backward + weight gradients 3 bf16 parts / 6 MFMAs)",
+              "train_fwd_x3_kernel<256> + train_bwd_kernel<X6,256>", "mlp_x6_kernel<256,MC> (scheme X3)", 3, 6, 6, PEAK_BF16_MFMA_TFLOPS),
+    "f32x6g3": ("f32 (as f32x6; backward chain in 2 fp16 parts / 3 MFMAs on row-normalised gradients, weight gradients from 2 bf16 "
+                "parts / 3 MFMAs: ~5e-6 relative gradient error)",
+                "train_fwd_x3_kernel<256> + train_bwd_kernel<X3,256>", "mlp_x6_kernel<256,MC> (scheme X3)", 3, 3, 3, PEAK_BF16_MFMA_TFLOPS),
+    "fp32": ("f32 (exact: v_mfma_f32_*_f32)", "train_chain_kernel<256>", "mlp_kernel<256,MC>", 1, 1, 1, PEAK_FP32_MFMA_TFLOPS),
     "bf16": ("bf16 MFMA inputs, f32 accumulate/activations/loss/master weights (parity rtol 2e-2)",
-             "train_chain_bf16_kernel<256>", "mlp_bf16_kernel<256,MC>", PEAK_BF16_MFMA_TFLOPS),
+             "train_chain_bf16_kernel<256>", "mlp_bf16_kernel<256,MC>", 1, 1, 1, PEAK_BF16_MFMA_TFLOPS),
 }
+HALF_CHAIN_FLOP_PER_ROW = CHAIN_FLOP_PER_ROW // 2          # forward 2 (M - 8H) = backward 2 (M - 8H): the K = 8 input layer is exact f32
 
 
 def parse():
@@ -443,7 +454,7 @@ def main():
     def measure(precision, warmup, steps):
         """Timed steps, per-phase kernel times (events on the launch stream) and the MC-dropout launch in one precision."""
         model.dnn.set_precision(precision)
-        dtype, chain_kernel, fwd_kernel, peak = PRECISIONS[precision]
+        dtype, chain_kernel, fwd_kernel, pf, pb, pw, peak1 = PRECISIONS[precision]
         model.dnn.train()
         for _ in range(warmup):
             one_step()
@@ -464,14 +475,26 @@ def main():
                 _ptr(loss_buf), _ptr(work), work.numel(), _stream(), ph), "phases")
         reps = max(3, min(10, steps))
         ms_chain, ms_wgrad, ms_reduce = time_events(phase(1), reps), time_events(phase(2), reps), time_events(phase(4), reps)
+        ms_fwd, ms_bwd = time_events(phase(8), reps), time_events(phase(16), reps)        # (not separate kernels in the fp32 / bf16 families)
         achieved = CHAIN_FLOP_PER_ROW * rows / (ms_chain * 1e-3) / 1e12
+        # executed matrix FLOP of the chain per algorithmic FLOP: forward half x pf, backward half x pb
+        chain_peak = peak1 / ((pf + pb) / 2.0)
         wg = FWD_FLOP_PER_ROW * rows / (ms_wgrad * 1e-3) / 1e12
-        r["roofline"] = {"kernel": chain_kernel, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "flop_per_row": CHAIN_FLOP_PER_ROW, "ms": ms_chain,
-                         "wgrad": {"ms": ms_wgrad, "achieved": wg, "frac": wg / (PEAK_BF16_MFMA_TFLOPS / 3.0 if precision == "f32x6g3" else peak)},
+        step_exec = (HALF_CHAIN_FLOP_PER_ROW * (pf + pb) + FWD_FLOP_PER_ROW * pw) * rows       # executed MFMA FLOP of a whole step
+        r["roofline"] = {"kernel": chain_kernel, "bound": "mfma", "achieved": achieved, "peak": chain_peak, "unit": "TFLOP/s",
+                         "frac": achieved / chain_peak, "traffic": None, "flop_per_row": CHAIN_FLOP_PER_ROW, "ms": ms_chain,
+                         "products_per_mac": {"forward": pf, "backward": pb, "wgrad": pw},
+                         "frac_if_priced_at_6_products": achieved / (peak1 / 6.0),
+                         "wgrad": {"ms": ms_wgrad, "achieved": wg, "frac": wg / (peak1 / pw)},
                          "reduce_ms": ms_reduce,
-                         "step_mfma_frac": STEP_FLOP_PER_ROW * rows / (r["ms_per_step"] * 1e-3) / 1e12 / peak,
+                         "step_mfma_frac": step_exec / (r["ms_per_step"] * 1e-3) / 1e12 / peak1,
                          "hbm_algorithmic_GBps": 36.0 * rows / (r["ms_per_step"] * 1e-3) / 1e9}
+        if precision.startswith("f32x6"):
+            fa = HALF_CHAIN_FLOP_PER_ROW * rows / (ms_fwd * 1e-3) / 1e12
+            ba = HALF_CHAIN_FLOP_PER_ROW * rows / (ms_bwd * 1e-3) / 1e12
+            r["roofline"]["kernels"] = {
+                chain_kernel.split(" + ")[0]: {"ms": ms_fwd, "achieved": fa, "peak": peak1 / pf, "frac": fa / (peak1 / pf)},
+                chain_kernel.split(" + ")[1]: {"ms": ms_bwd, "achieved": ba, "peak": peak1 / pb, "frac": ba / (peak1 / pb)}}
         if not args.no_mc:
             T = args.mc_passes
             for m in model.dnn.dropout_modules():
@@ -485,8 +508,10 @@ def main():
             mc_tf = FWD_FLOP_PER_ROW * rows * (T + 1) / mc_s / 1e12
             r["mc_dropout"] = {"metric": "mc_dropout_fwd_passes_per_s", "value": n_global * T / mc_s, "unit": "fwd-passes/s",
                                "rows_per_gpu": rows, "passes": T, "seconds": mc_s,
-                               "roofline": {"kernel": fwd_kernel, "bound": "mfma", "achieved": mc_tf, "peak": peak, "unit": "TFLOP/s",
-                                            "frac": mc_tf / peak, "hbm_algorithmic_GBps": 44.0 * rows / mc_s / 1e9},
+                               "roofline": {"kernel": fwd_kernel, "bound": "mfma", "achieved": mc_tf, "peak": peak1 / pf, "unit": "TFLOP/s",
+                                            "frac": mc_tf / (peak1 / pf), "products_per_mac": pf,
+                                            "frac_if_priced_at_6_products": mc_tf / (peak1 / 6.0),
+                                            "hbm_algorithmic_GBps": 44.0 * rows / mc_s / 1e9},
                                "e_u_mean": float(eu.mean().item())}
             for m in model.dnn.dropout_modules():
                 m.p = 0.2
@@ -535,7 +560,7 @@ def main():
 
     # ------------------------------------------------------------------ extra legs: the same measurement in the other precisions
     if not args.only:
-        extras = [("exact_fp32", "fp32")] + ([] if args.no_bf16 else [("bf16_mixed", "bf16")])
+        extras = [("exact_fp32", "fp32")] + ([] if args.no_bf16 else [("bf16_mixed", "bf16")]) + [("f32x6_g3_opt_in", "f32x6g3")]
         for name, prec in extras:
             if prec == args.precision:
                 continue
@@ -556,7 +581,7 @@ def main():
     # stash (3.84 KB/row) and the d pre-activations (3.84 KB/row) written by the chain, the stash read back by it and both
     # read by the weight-gradient kernels -- over the same times; which roof binds is the larger fraction
     r = out["roofline"]
-    chain_bytes, wgrad_bytes = (36 + 3 * 3840 + 2 * 384) * rows, (2 * 3840 + 32 + 8) * rows
+    chain_bytes, wgrad_bytes = (36 + 3 * 3840 + 3 * 256 + 2 * 8) * rows, (2 * 3840 + 32 + 8) * rows      # (+ v2 and du, dz across the kernel seam)
     out["roofline_hbm_design"] = {
         "bound": "hbm", "unit": "GB/s", "peak": 8000.0,
         "chain": {"bytes": chain_bytes, "achieved": chain_bytes / (r["ms"] * 1e-3) / 1e9, "frac": chain_bytes / (r["ms"] * 1e-3) / 1e9 / 8000.0},

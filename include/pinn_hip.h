@@ -218,6 +218,10 @@ int pinn_mlp_train_grads(const pinn_net_t* net, const float* d_params, const flo
 #define PINN_PHASE_WGRAD 2u   /* the per-layer weight-gradient kernels (read the stash)              */
 #define PINN_PHASE_REDUCE 4u  /* fixed-order slab reduction -> d_grads, d_loss                       */
 #define PINN_PHASE_ALL 7u
+/* PINN_PREC_F32X6 / _G3 on the fused nets (hidden <= 256): the chain is two kernels, forward (+ loss) and backward; either
+ * alone (the other precisions and the wide nets treat these two bits like PINN_PHASE_CHAIN) */
+#define PINN_PHASE_CHAIN_FWD 8u
+#define PINN_PHASE_CHAIN_BWD 16u
 int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y,
                                 long long n_rows, long long n_global, const pinn_dropout_t* drop,
                                 float* d_grads, double* d_loss, void* d_work, size_t work_bytes, void* stream,

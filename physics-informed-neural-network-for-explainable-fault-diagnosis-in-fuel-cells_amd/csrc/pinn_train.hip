@@ -548,7 +548,8 @@ static int dispatch_wgrad(const WgradArgs& a, hipStream_t st) {
 
 namespace pinn {
 int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y, long long n_rows,
-                          long long n_global, const DropDev& drop, const TrainBuffers& b, int* grid_out, void* stream);   // pinn_x6_train.hip
+                          long long n_global, const DropDev& drop, const TrainBuffers& b, unsigned which, int* grid_out,
+                          void* stream);   // pinn_x6_train.hip; which: 1 = forward kernel, 2 = backward kernel, 3 = both
 int launch_train_chain_wide(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y, long long n_rows,
                             long long n_global, const DropDev& drop, const TrainBuffers& b, int* grid_out, void* stream);  // pinn_wide.hip
 int launch_train_bf16(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y, long long n_rows,
@@ -570,6 +571,9 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
   if (rc) return rc;
   if (!d_params || !d_x || !d_y || !d_grads || !d_loss || !d_work || n_rows <= 0 || n_global < n_rows) return PINN_E_ARG;
   if (((unsigned long long)d_grads | (unsigned long long)d_work) & 15) return PINN_E_ARG;      // 16-B vector accesses
+  // the forward / backward halves are separate kernels only in the fused x6 path; elsewhere either bit means the chain
+  if (!(net->precision >= PINN_PREC_F32X6 && net->hidden <= 256) && (phases & (PINN_PHASE_CHAIN_FWD | PINN_PHASE_CHAIN_BWD)))
+    phases |= PINN_PHASE_CHAIN;
   const Workspace w = plan_workspace(net, n_rows);
   if (work_bytes < w.total) return PINN_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -628,14 +632,15 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
   }
   if (net->precision >= PINN_PREC_F32X6) {
     // fp32-accurate chain on the bf16 matrix cores; the weight-gradient and finalize kernels below are shared
-    if (phases & PINN_PHASE_CHAIN) {
+    if (phases & (PINN_PHASE_CHAIN | PINN_PHASE_CHAIN_FWD | PINN_PHASE_CHAIN_BWD)) {
+      const unsigned which = (phases & PINN_PHASE_CHAIN) ? 3u : (((phases & PINN_PHASE_CHAIN_FWD) ? 1u : 0u) | ((phases & PINN_PHASE_CHAIN_BWD) ? 2u : 0u));
       TrainBuffers b{};
       b.stash_h = a.stash_h; b.stash_v1 = a.stash_v1; b.stash_v2 = a.stash_v2;
       b.dpre_h = a.dpre_h; b.dpre_v1 = a.dpre_v1; b.dpre_v2 = a.dpre_v2;
       b.keep = a.keep; b.du = a.du; b.dz = a.dz; b.loss_part = a.loss_part;
       b.slabs = (float*)(base + w.off_slabs); b.t16 = w.t16; b.n_slices = w.n_slices;
       rc = H > 256 ? launch_train_chain_wide(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, &grid, stream)
-                   : launch_train_chain_x6(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, &grid, stream);
+                   : launch_train_chain_x6(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, which, &grid, stream);
       if (rc) return rc;
     } else if (H > 256) {
       const long long t4 = w.t16 / 4;

@@ -155,7 +155,7 @@ void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st
 
 // chain phase of pinn_mlp_train_grads for PINN_PREC_F32X6; *grid_out = workgroups (= loss partials)
 int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y, long long n_rows,
-                          long long n_global, const DropDev& drop, const TrainBuffers& b, int* grid_out, void* stream) {
+                          long long n_global, const DropDev& drop, const TrainBuffers& b, unsigned which, int* grid_out, void* stream) {
   using namespace x6;
   hipStream_t st = (hipStream_t)stream;
   launch_pack_x6(net, d_params, st);
@@ -177,19 +177,15 @@ int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const fl
   const __bf16* packed = (const __bf16*)net->d_packed;
   const bool bits = drop.mode == PINN_DROP_BITS;
   const bool fast_bwd = net->precision == PINN_PREC_F32X6_G3;        // opt-in: the backward chain in scheme X3 too
-#ifdef PINN_X6_NOBWD
-  constexpr bool fwd_only = true;        // measurement builds: the forward kernel alone
-#else
-  constexpr bool fwd_only = false;
-#endif
+  const bool run_fwd = which & 1u, fwd_only = !(which & 2u);
 #define PINN_LAUNCH_T(HH, BB)                                                                                                   \
   do {                                                                                                                          \
     if (small_n) {                                                                                                              \
-      hipLaunchKernelGGL((train_fwd_x3_kernel<HH, BB, 4>), dim3(grid), dim3(256), 0, st, a, packed);                            \
+      if (run_fwd) hipLaunchKernelGGL((train_fwd_x3_kernel<HH, BB, 4>), dim3(grid), dim3(256), 0, st, a, packed);               \
       if (!fwd_only && fast_bwd) hipLaunchKernelGGL((train_bwd_kernel<X3, HH, 4>), dim3(grid), dim3(256), 0, st, a, packed);    \
       else if (!fwd_only) hipLaunchKernelGGL((train_bwd_kernel<X6, HH, 4>), dim3(grid), dim3(256), 0, st, a, packed);           \
     } else {                                                                                                                    \
-      hipLaunchKernelGGL((train_fwd_x3_kernel<HH, BB, 8>), dim3(grid), dim3(512), 0, st, a, packed);                            \
+      if (run_fwd) hipLaunchKernelGGL((train_fwd_x3_kernel<HH, BB, 8>), dim3(grid), dim3(512), 0, st, a, packed);               \
       if (!fwd_only && fast_bwd) hipLaunchKernelGGL((train_bwd_kernel<X3, HH, 8>), dim3(grid), dim3(512), 0, st, a, packed);    \
       else if (!fwd_only) hipLaunchKernelGGL((train_bwd_kernel<X6, HH, 8>), dim3(grid), dim3(512), 0, st, a, packed);           \
     }                                                                                                                           \
