@@ -76,9 +76,6 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #else
 #define PINN_RING_AUX 0
 #endif
-#ifdef PINN_ABL_PRIO
-#define PINN_ABL_PRIO_YOUNG (threadIdx.x >= 256 && blockDim.x == 512)
-#endif
 #ifdef PINN_X6_STAMP
 // diagnostic build only: per-wave cycle sums of the segments of a slab step (first phase, second phase,
 // wait + barrier), read back with pinn_x6_debug_read()
@@ -332,10 +329,6 @@ struct X3 {
 template <typename S, int MT, int NTOUT, typename V, typename D>
 __device__ __forceinline__ void slab_pair(f32x4 (&acc)[NTOUT], const typename S::Frag& b, unsigned addr, typename S::AFrag& a0,
                                           typename S::AFrag& a1, V&& vchunk, D&& dma) {
-#ifdef PINN_ABL_PRIO
-  if constexpr (MT == 0) { if (PINN_ABL_PRIO_YOUNG) __builtin_amdgcn_s_setprio(1); }
-  if constexpr (MT == NTOUT / 2 && NTOUT >= 4) { if (PINN_ABL_PRIO_YOUNG) __builtin_amdgcn_s_setprio(0); }
-#endif
   S::template wait<S::kCopies>(a0);                 // a1 (issued after a0) may still be in flight
   S::mma(acc[MT], a0, b);
   __builtin_amdgcn_sched_barrier(0);
@@ -455,11 +448,14 @@ __device__ __forceinline__ void prep_micro(PrepBase& s, f32x4& v0, f32x4& v1, co
     if constexpr (!kBits && par == 0) philox_rounds5<5>(s, d.seed_lo, d.seed_hi);
   } else if constexpr (k < 6) {
     constexpr int r = k - 2;
-    const float a0 = tanh_pre(v0[r], pre), a1 = tanh_pre(v1[r], pre);
+    // scale * tanh(x) = scale - 2 scale / (e^{2x} + 1): the dropout / operand scale rides in the tanh's last fma
+    const float m2s = -2.0f * ld.scale;
+    const float a0 = fmaf(m2s, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v0[r] * pre) + 1.0f), ld.scale);
+    const float a1 = fmaf(m2s, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v1[r] * pre) + 1.0f), ld.scale);
     const bool k0 = kBits ? ((s.keep >> r) & 1u) != 0 : keep_draw<par, 0, r>(s, ld.thr);
     const bool k1 = kBits ? ((s.keep >> (4 + r)) & 1u) != 0 : keep_draw<par, 1, r>(s, ld.thr);
-    const float hs0 = k0 ? a0 * ld.scale : 0.0f;          // the matrix operand: S::kActScale x the activation
-    const float hs1 = k1 ? a1 * ld.scale : 0.0f;
+    const float hs0 = k0 ? a0 : 0.0f;                      // the matrix operand: S::kActScale x the activation
+    const float hs1 = k1 ? a1 : 0.0f;
     S::template split<r>(hs0, hs1, out);
     float h0 = hs0, h1 = hs1;                              // the activation itself (stash, predict head)
     if constexpr (S::kActScale != 1.0f) {
@@ -474,17 +470,11 @@ __device__ __forceinline__ void prep_micro(PrepBase& s, f32x4& v0, f32x4& v1, co
     }
   } else {
     if (sp) {
-#ifdef PINN_ABL_WIDESTORE      // timing experiment only: same bytes, same 2-KB region, two 16-B stores per lane (WRONG layout)
-      float* q = sp - (4 * c.kq * 16 + (c.lane & 15)) + c.lane * 8;
-      *reinterpret_cast<f32x4*>(q) = v0;
-      *reinterpret_cast<f32x4*>(q + 4) = v1;
-#else
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         PINN_STASH_ST(sp + r * 16, v0[r]);
         PINN_STASH_ST(sp + (16 + r) * 16, v1[r]);
       }
-#endif
     }
   }
 }
@@ -517,16 +507,6 @@ __device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], typename S::Pipe& 
     constexpr int g = decltype(gc)::value;
     // the next slab: K-group g + 1 of this matrix, or K-group 0 of the next one
     auto dma = [&](auto slotc) {
-#ifdef PINN_ABL_ROTDMA
-      // experiment: the eight waves issue their pieces in different pair-slots (rotated by the wave index), so that the
-      // CU's 64-B/clk vector-memory path sees one or two pieces per slot instead of eight at once
-      if constexpr (NTOUT == 16 && WAVES == 8) {
-        const int j = (decltype(slotc)::value - pipe.wave) & 7;
-        if constexpr (g + 1 < NG) { if (WAVES * j < NPM) pipe.template piece<KPM, WAVES>(mine, g + 1, j, pipe.par ^ 1); }
-        else { if (WAVES * j < NPN) pipe.template piece<KPN, WAVES>(next, 0, j, pipe.par ^ 1); }
-        return;
-      }
-#endif
       static_for<kPerDma>([&](auto qc) {
         constexpr int j = decltype(slotc)::value * kPerDma + decltype(qc)::value;
         if constexpr (g + 1 < NG) {
