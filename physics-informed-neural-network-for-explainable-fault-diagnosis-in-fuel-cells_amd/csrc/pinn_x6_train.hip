@@ -176,11 +176,7 @@ int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const fl
   *grid_out = grid;
   const __bf16* packed = (const __bf16*)net->d_packed;
   const bool bits = drop.mode == PINN_DROP_BITS;
-#ifdef PINN_EXP_X3BWD
-  const bool fast_bwd = true;
-#else
   const bool fast_bwd = net->precision == PINN_PREC_F32X6_G3;        // opt-in: the backward chain in scheme X3 too
-#endif
   const bool run_fwd = which & 1u, fwd_only = !(which & 2u);
 #define PINN_LAUNCH_T(HH, BB)                                                                                                   \
   do {                                                                                                                          \
