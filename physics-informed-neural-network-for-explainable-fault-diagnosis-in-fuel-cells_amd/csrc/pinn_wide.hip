@@ -3,13 +3,15 @@
 //
 // Activations live in HBM between layers, in the stash layout [tile16][feature][16 rows] fp32 (scratch behind the
 // packed weights in pinn_net_t.d_packed; rows are processed in chunks of kWideChunk).  One layer kernel: a wave owns
-// 16 rows and computes 128 output features at a time (8 accumulator blocks); per 32-feature K-group the weight slab
-// (3 bf16 copies x 128 rows x 64 B) streams global -> LDS by LDS-DMA exactly as in the chain, and the B operand is
+// 16 rows and computes 256 (or 128) output features at a time (16 / 8 accumulator blocks); per 32-feature K-group the weight
+// slab (the scheme's copies x 256 rows x 64 B) streams global -> LDS by LDS-DMA exactly as in the chain, and the B operand is
 // the input activation block (2 KB per wave and group), fetched by LDS-DMA two groups ahead into a per-wave ring and
-// split (hi, mid, lo) one group ahead, between the MFMA groups of the current slab.  Epilogue per 128 features:
+// split one group ahead, between the MFMA groups of the current slab.  Epilogue per pass:
 // bias is in the accumulator; tanh + Philox dropout (the same stream as every other kernel: keyed by global row,
 // layer, feature) -> next layer's input, or (backward) times the activation derivative -> d pre-activation.
-// fp32-accurate (PINN_PREC_F32X6 arithmetic); parity-tested, not tuned.
+// Arithmetic as in the fused nets (PINN_PREC_F32X6): forward layers in scheme X3 (two fp16 parts, three MFMAs per product:
+// activations x 8 at the split, weights x 64 in the packed copies, the factor 512 leaves in the epilogue), backward layers in
+// x6 (three bf16 parts, six MFMAs).
 #include "pinn_x6_core.h"
 
 namespace pinn {
@@ -30,7 +32,7 @@ __device__ __forceinline__ unsigned activate_pair_rt(f32x4& v0, f32x4& v1, const
 
 struct LayerArgs {
   const float* params;       // flat fp32 parameters (biases, init weights)
-  const char* packed;        // three bf16 copies
+  const char* packed;        // the scheme's copies: three bf16 ones (x6), or the two fp16 ones behind them (X3)
   unsigned copy_bytes;
   const float* in;           // [T16][IN][16]
   float* out;                // [T16][OUT][16]
@@ -47,37 +49,29 @@ struct LayerArgs {
   unsigned pass;
 };
 
-// runtime-stride twin of Pipe6::piece
-__device__ __forceinline__ void piece_rt(Pipe6& pipe, unsigned off, int kp_log, int nrb_log, int j, int buf) {
-  int p = pipe.wave + 8 * j;
-  const int n = 3 << nrb_log;
-  p = p < n ? p : p - n;
-  asm volatile("" : "+s"(p));
-  const unsigned voff = (pipe.lane_row2 << kp_log) + pipe.lane_kq8;
-  const int copy = p >> nrb_log, rb = p & ((1 << nrb_log) - 1);
-  const unsigned soff = (unsigned)copy * pipe.copy_bytes + 2u * (off + ((unsigned)(rb * 16) << kp_log));
-  char* dst = pipe.lds + buf * kSlabBytes + copy * (kSlabBytes / 3) + rb * 1024;
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(pipe.rsrc, (lptr_t)dst, 16, voff, soff, 0, 0);
-}
-
 // kNT accumulator blocks = 16 kNT output features per pass over the K-groups: 16 (256 features, half the input
 // re-reads and fragment splits) when OUT allows, else 8
-template <int EPI, int kNT>
+template <typename S, int EPI, int kNT>
 __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a) {
-  constexpr int kOB = 16 * kNT, kNrb = kNT == 16 ? 4 : 3, kPieces = (3 << kNrb) / 8;     // features per pass; log2(16-row blocks); pieces per wave
+  using Pipe = typename S::Pipe;
+  using Frag = typename S::Frag;
+  constexpr int kOB = 16 * kNT, kNrb = kNT == 16 ? 4 : 3;                 // features per pass; log2(16-row blocks)
+  constexpr int kPieces = ((S::kCopies << kNrb) + 7) / 8;                 // LDS-DMA pieces per wave and slab
+  static_assert((S::kCopies << kNrb) % 8 == 0, "pieces must divide over the eight waves");
   constexpr int kRingBytes = 8 * 2 * 2048;
   constexpr int kSlabAt = (kRingBytes + 1023) & ~1023;
-  __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * kSlabBytes];
-  Pipe6 pipe;
+  constexpr float kAct = S::kActScale, kAcc = S::kAccScale, kInvAcc = 1.0f / S::kAccScale;
+  __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * Pipe::kSlab];
+  Pipe pipe;
   pipe.lds = smem + kSlabAt;
   pipe.init(a.packed, a.copy_bytes, threadIdx.x);
   const int lane = threadIdx.x & 63, wave = pipe.wave, kq = lane >> 4;
   const StashRing ring{smem + wave * 4096, lane};
   const int NG = a.IN / 32, nob = a.OUT / kOB;
-  auto slab_off = [&](int ob, int g) { return a.mat_off + ((unsigned)(ob * kOB) << a.kp_log) + 32u * (unsigned)g; };
+  auto slab_mat = [&](int ob) { return Mat{a.mat_off + ((unsigned)(ob * kOB) << a.kp_log), kNrb, a.kp_log}; };      // the rows of pass ob
   // slab (0, 0)
   pipe.par = 0;
-  for (int j = 0; j < kPieces; ++j) piece_rt(pipe, slab_off(0, 0), a.kp_log, kNrb, j, 0);
+  for (int j = 0; j < kPieces; ++j) pipe.template piece<-1>(slab_mat(0), 0, j, 0);
   __syncthreads();
 
   const long long n_tiles = (a.n_rows + kTileRowsX - 1) / kTileRowsX;
@@ -92,10 +86,10 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
     fetch(0);
     fetch(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    Frag3 cur, nxt;
+    Frag cur, nxt;
     static_for<4>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
-      split_pair<r>(ring.read(0, 0, r), ring.read(0, 1, r), cur);
+      S::template split<r>(ring.read(0, 0, r) * kAct, ring.read(0, 1, r) * kAct, cur);
     });
 #pragma unroll 1
     for (int ob = 0; ob < nob; ++ob) {
@@ -109,18 +103,22 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
         }
       } else {
         bias_blocks<kNT>(acc, a.params + a.bias_off + ob * kOB, kq);
+        if constexpr (kAcc != 1.0f) {
+#pragma unroll
+          for (int t = 0; t < kNT; ++t) acc[t] = acc[t] * kAcc;
+        }
       }
 #pragma unroll 1
       for (int g = 0; g < NG; ++g) {
         // next slab, next block to split (g + 1), block to fetch (g + 2); the input blocks repeat for every ob
         const bool last_g = g + 1 == NG;
         const int ob2 = last_g ? (ob + 1 < nob ? ob + 1 : 0) : ob, g2 = last_g ? 0 : g + 1;
-        const unsigned off2 = slab_off(ob2, g2);
+        const Mat m2 = slab_mat(ob2);
         const int gb = g2, gf = g + 2 < NG ? g + 2 : g + 2 - NG;
         // slots = tile pairs (kNT / 2): the weight pieces first, the ring fetch in the last one
         auto dma = [&](auto slotc) {
           constexpr int slot = decltype(slotc)::value;
-          if constexpr (slot < kPieces) piece_rt(pipe, off2, a.kp_log, kNrb, slot, pipe.par ^ 1);
+          if constexpr (slot < kPieces) pipe.template piece<-1>(m2, g2, slot, pipe.par ^ 1);
           if constexpr (slot == kNT / 2 - 1) fetch(gf);
         };
         // chunks = tiles: the four register pairs of the next block, evenly spread
@@ -128,14 +126,18 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
           constexpr int ci = decltype(cc)::value, every = kNT / 4;
           if constexpr (ci % every == every - 1) {
             constexpr int r = ci / every;
-            split_pair<r>(ring.read(gb & 1, 0, r), ring.read(gb & 1, 1, r), nxt);
+            S::template split<r>(ring.read(gb & 1, 0, r) * kAct, ring.read(gb & 1, 1, r) * kAct, nxt);
           }
         };
-        slab_mfma<X6, kNT>(acc, cur, pipe.cur(), lane, vchunk, dma);
+        slab_mfma<S, kNT>(acc, cur, pipe.cur(), lane, vchunk, dma);
         pipe.advance();
         cur = nxt;
       }
-      // ---- epilogue of these 128 output features
+      // ---- epilogue of these output features (X3: the accumulators carry 512 x the pre-activation)
+      if constexpr (kAcc != 1.0f) {
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) acc[t] = acc[t] * kInvAcc;
+      }
       float* out_tile = a.out + (t16 * a.OUT + ob * kOB + 4 * kq) * 16 + (lane & 15);
       if (EPI == EPI_BACKWARD) {
         const float scale = a.drop.mode != PINN_DROP_NONE ? a.drop.scale[a.layer] : 1.0f, inv_scale = 1.0f / scale;
@@ -379,10 +381,17 @@ void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st
 }
 
 // scratch behind the packed weights (floats): two activation buffers, v1, v2, the MC sums
+// forward layers: scheme X3 on the fp16 copies (behind the three bf16 ones); backward layers: x6
 template <int EPI>
-static void launch_wide_layer(const wide::LayerArgs& la, int grid, hipStream_t st) {
-  if (la.OUT % 256 == 0) hipLaunchKernelGGL((wide::wide_layer_x6_kernel<EPI, 16>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
-  else hipLaunchKernelGGL((wide::wide_layer_x6_kernel<EPI, 8>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
+static void launch_wide_layer(wide::LayerArgs la, int grid, hipStream_t st) {
+  if constexpr (EPI == wide::EPI_BACKWARD) {
+    if (la.OUT % 256 == 0) hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::X6, EPI, 16>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
+    else hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::X6, EPI, 8>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
+  } else {
+    la.packed += 3 * (size_t)la.copy_bytes;
+    if (la.OUT % 256 == 0) hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::X3, EPI, 16>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
+    else hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::X3, EPI, 8>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
+  }
 }
 
 size_t wide_scratch_floats(int H) {
@@ -401,7 +410,7 @@ int launch_forward_wide(const pinn_net_t* net, const FwdArgs& fa, bool mc, void*
   x6::launch_pack_x6(net, fa.params, st);
   const char* packed = (const char*)net->d_packed;
   const unsigned copy_bytes = (unsigned)(K.total() * 2);
-  float* scratch = (float*)((char*)net->d_packed + (size_t)K.total() * 2 * 3);
+  float* scratch = (float*)((char*)net->d_packed + (size_t)K.total() * 2 * 5);
   float* bufA = scratch; float* bufB = bufA + (size_t)kWideChunk * H;
   float* v1 = bufB + (size_t)kWideChunk * H; float* v2 = v1 + (size_t)kWideChunk * (H / 2);
   float* accum = v2 + (size_t)kWideChunk * (H / 4);

@@ -10,7 +10,7 @@ struct PackJobs6 {
   PackJob j[18];
   int n;
   long long copy_stride;
-  int with_f16;          // fused nets: also the two fp16 copies of the forward matrices (scheme X3)
+  int with_f16;          // also the two fp16 copies (scheme X3)
 };
 
 static int cu_count_x() { return cu_count_cached(); }
@@ -63,7 +63,7 @@ void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st
   add(K.wv1t(), L.wv1(), H / 2, H / 4, H / 2, 1);
   jobs.n = n;
   jobs.copy_stride = K.total();
-  jobs.with_f16 = H <= 256;        // (wide nets run x6 layer kernels; that region is their activation scratch)
+  jobs.with_f16 = 1;
   hipLaunchKernelGGL(pack_x6_kernel, dim3(64, n), dim3(256), 0, st, d_params, (__bf16*)net->d_packed, jobs);
 }
 
