@@ -159,9 +159,9 @@ int pinn_net_f_t(const float* d_x, const float* d_u, const float* d_x_halo, cons
 #define PINN_PREC_BF16 1  /* bf16 MFMA inputs, fp32 accumulate / activations / loss / master weights (rtol ~2e-2)    */
 #define PINN_PREC_F32X6 2 /* fp32-ACCURATE matrix math on the 16-bit matrix cores from split operands, fp32 accumulation; same
                              tolerances as PINN_PREC_FP32, 1.7-3x faster.  Forward passes (pinn_mlp_forward, pinn_mc_dropout,
-                             the forward half of pinn_mlp_train_grads) on the fused nets: two fp16 parts, three MFMAs per
-                             product (as accurate as an fp32 matmul); backward chain, weight gradients and the wide nets:
-                             three bf16 parts, six MFMAs per product.  What the Python surface uses by default. */
+                             the forward half of pinn_mlp_train_grads; fused and wide nets): two fp16 parts, three MFMAs
+                             per product (as accurate as an fp32 matmul); backward chain and weight gradients: three bf16
+                             parts, six MFMAs per product.  What the Python surface uses by default. */
 #define PINN_PREC_F32X6_G3 3 /* as F32X6, but gradients too from two parts (backward chain: fp16 parts of per-row-normalised
                                 gradients; weight gradients: two bf16 parts): gradient tensors ~5e-6 of their largest
                                 element from float64 instead of ~3e-7, small elements relatively worse.  Opt-in. */
