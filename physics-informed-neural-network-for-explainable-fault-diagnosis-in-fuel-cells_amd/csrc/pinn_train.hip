@@ -477,7 +477,7 @@ static Workspace plan_workspace(const pinn_net_t* net, long long n_rows) {
   Workspace w;
   const long long H = net->hidden, nh = net->n_hidden;
   // whole workgroup tiles: 64 rows (4 wave tiles), 128 (8) for the x6 chain
-  w.t16 = net->precision >= PINN_PREC_F32X6 ? (n_rows + 127) / 128 * 8 : (n_rows + kTileRows - 1) / kTileRows * 4;
+  w.t16 = (net->precision >= PINN_PREC_F32X6 || net->hidden > 256) ? (n_rows + 127) / 128 * 8 : (n_rows + kTileRows - 1) / kTileRows * 4;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
   w.off_stash_h = take((size_t)nh * w.t16 * H * 16 * 4);
@@ -505,7 +505,7 @@ static int check_net_t(const pinn_net_t* net) {
   if (net->hidden != 128 && net->hidden != 256 && !wide) return PINN_E_ARCH;
   if (net->n_hidden < 1 || net->n_hidden > 8) return PINN_E_ARCH;
   if (net->precision < PINN_PREC_FP32 || net->precision > PINN_PREC_F32X6_G3) return PINN_E_ARG;
-  if (wide && net->precision < PINN_PREC_F32X6) return PINN_E_ARCH;
+  if (wide && net->precision == PINN_PREC_FP32) return PINN_E_ARCH;
   if (net->precision != PINN_PREC_FP32 && !net->d_packed) return PINN_E_ARG;
   return PINN_OK;
 }
@@ -617,7 +617,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
   const long long n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   int grid = (int)(n_tiles < 2 * cu_count() ? n_tiles : 2 * cu_count());
   if (grid > 1024) grid = 1024;
-  if (net->precision == PINN_PREC_BF16) {
+  if (net->precision == PINN_PREC_BF16 && H <= 256) {
     TrainBuffers b{};
     b.stash_h = a.stash_h; b.stash_v1 = a.stash_v1; b.stash_v2 = a.stash_v2;
     b.dpre_h = a.dpre_h; b.dpre_v1 = a.dpre_v1; b.dpre_v2 = a.dpre_v2;
@@ -630,8 +630,8 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     hipError_t eb = hipGetLastError();
     return eb == hipSuccess ? PINN_OK : (int)eb;
   }
-  if (net->precision >= PINN_PREC_F32X6) {
-    // fp32-accurate chain on the bf16 matrix cores; the weight-gradient and finalize kernels below are shared
+  if (net->precision >= PINN_PREC_F32X6 || H > 256) {
+    // split-operand chain on the 16-bit matrix cores (wide nets: also bf16-mixed); the weight-gradient and finalize kernels below are shared
     if (phases & (PINN_PHASE_CHAIN | PINN_PHASE_CHAIN_FWD | PINN_PHASE_CHAIN_BWD)) {
       const unsigned which = (phases & PINN_PHASE_CHAIN) ? 3u : (((phases & PINN_PHASE_CHAIN_FWD) ? 1u : 0u) | ((phases & PINN_PHASE_CHAIN_BWD) ? 2u : 0u));
       TrainBuffers b{};
@@ -671,7 +671,8 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     g.s1 = nullptr; g.dvq = nullptr; g.s2 = nullptr; g.R = nullptr; g.dvr = nullptr;
     if ((rc = dispatch_wgrad(g, st))) return rc;
     // every layer but the input one: split-bf16 products on the matrix cores for PINN_PREC_F32X6
-    const int ns = net->precision == PINN_PREC_F32X6 ? 3 : (net->precision == PINN_PREC_F32X6_G3 ? 2 : 0);   // bf16 parts per operand
+    // bf16 parts per operand (0: exact fp32 kernels; 1: bf16-mixed on the wide nets)
+    const int ns = net->precision == PINN_PREC_F32X6 ? 3 : (net->precision == PINN_PREC_F32X6_G3 ? 2 : (net->precision == PINN_PREC_BF16 ? 1 : 0));
     auto wgrad = [&](const WgradArgs& wa) { return ns ? dispatch_wgrad_x6(wa, ns, stream) : dispatch_wgrad(wa, st); };
     for (int l = 1; l < nh; ++l) {
       g.P = a.dpre_h + l * hs; g.Q = a.stash_h + (l - 1) * hs; g.OUT = H; g.IN = H; g.dW = slabs + L.w(l); g.db = slabs + L.b(l);

@@ -381,10 +381,14 @@ void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st
 }
 
 // scratch behind the packed weights (floats): two activation buffers, v1, v2, the MC sums
-// forward layers: scheme X3 on the fp16 copies (behind the three bf16 ones); backward layers: x6
+// PINN_PREC_F32X6: forward layers in scheme X3 on the fp16 copies (behind the three bf16 ones), backward layers in x6;
+// PINN_PREC_BF16: one bf16 part per operand everywhere (the first bf16 copy)
 template <int EPI>
-static void launch_wide_layer(wide::LayerArgs la, int grid, hipStream_t st) {
-  if constexpr (EPI == wide::EPI_BACKWARD) {
+static void launch_wide_layer(wide::LayerArgs la, int grid, hipStream_t st, int precision) {
+  if (precision == PINN_PREC_BF16) {
+    if (la.OUT % 256 == 0) hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::B1, EPI, 16>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
+    else hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::B1, EPI, 8>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
+  } else if constexpr (EPI == wide::EPI_BACKWARD) {
     if (la.OUT % 256 == 0) hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::X6, EPI, 16>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
     else hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::X6, EPI, 8>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
   } else {
@@ -437,15 +441,15 @@ int launch_forward_wide(const pinn_net_t* net, const FwdArgs& fa, bool mc, void*
       for (int l = 1; l < nh; ++l) {
         la.in = cur; la.out = nxt; la.IN = H; la.OUT = H; la.mat_off = (unsigned)K.w(l); la.kp_log = 31 - __builtin_clz((unsigned)H);
         la.bias_off = L.b(l); la.layer = l;
-        launch_wide_layer<EPI_TANH_DROP>(la, grid_l, st);
+        launch_wide_layer<EPI_TANH_DROP>(la, grid_l, st, net->precision);
         float* t = cur; cur = nxt; nxt = t;
       }
       la.in = cur; la.out = v1; la.IN = H; la.OUT = H / 2; la.mat_off = (unsigned)K.wv0(); la.kp_log = 31 - __builtin_clz((unsigned)H);
       la.bias_off = L.bv0(); la.layer = nh;
-      launch_wide_layer<EPI_TANH_DROP>(la, grid_l, st);
+      launch_wide_layer<EPI_TANH_DROP>(la, grid_l, st, net->precision);
       la.in = v1; la.out = v2; la.IN = H / 2; la.OUT = H / 4; la.mat_off = (unsigned)K.wv1(); la.kp_log = 31 - __builtin_clz((unsigned)round_up64(H / 2));
       la.bias_off = L.bv1(); la.layer = nh + 1;
-      launch_wide_layer<EPI_TANH>(la, grid_l, st);
+      launch_wide_layer<EPI_TANH>(la, grid_l, st, net->precision);
       HeadArgs ha{fa.params, cur, v2, n, H, L.wp(), L.bp(), L.wv2(), L.bv2(), mc ? (pass < 0 ? 1 : 2) : 0,
                   fa.o0 + r0, mc ? nullptr : fa.o1 + r0, accum, kWideChunk, pass < 0 ? 0 : pass};
       hipLaunchKernelGGL(wide_heads_kernel, dim3(grid_s), dim3(256), 0, st, ha);
@@ -485,14 +489,14 @@ int launch_train_chain_wide(const pinn_net_t* net, const float* d_params, const 
   for (int l = 1; l < nh; ++l) {
     la.in = sh + (l - 1) * hs; la.out = sh + l * hs; la.IN = H; la.OUT = H; la.mat_off = (unsigned)K.w(l); la.kp_log = log2i(H);
     la.bias_off = L.b(l); la.layer = l;
-    launch_wide_layer<EPI_TANH_DROP>(la, grid_l, st);
+    launch_wide_layer<EPI_TANH_DROP>(la, grid_l, st, net->precision);
   }
   la.in = sh + (nh - 1) * hs; la.out = sv1; la.IN = H; la.OUT = H / 2; la.mat_off = (unsigned)K.wv0(); la.kp_log = log2i(H);
   la.bias_off = L.bv0(); la.layer = nh;
-  launch_wide_layer<EPI_TANH_DROP>(la, grid_l, st);
+  launch_wide_layer<EPI_TANH_DROP>(la, grid_l, st, net->precision);
   la.in = sv1; la.out = sv2; la.IN = H / 2; la.OUT = H / 4; la.mat_off = (unsigned)K.wv1(); la.kp_log = log2i(round_up64(H / 2));
   la.bias_off = L.bv1(); la.layer = nh + 1;
-  launch_wide_layer<EPI_TANH>(la, grid_l, st);
+  launch_wide_layer<EPI_TANH>(la, grid_l, st, net->precision);
 
   const long long t4 = b.t16 / 4;
   const int grid_loss = (int)(t4 < 1024 ? (t4 < 1 ? 1 : t4) : 1024);
@@ -504,15 +508,15 @@ int launch_train_chain_wide(const pinn_net_t* net, const float* d_params, const 
   la.init_w = nullptr; la.init_s = nullptr;
   la.in = dv2; la.out = dv1; la.act = sv1; la.IN = H / 4; la.OUT = H / 2; la.mat_off = (unsigned)K.wv1t(); la.kp_log = log2i(round_up64(H / 4));
   la.layer = nh;
-  launch_wide_layer<EPI_BACKWARD>(la, grid_l, st);
+  launch_wide_layer<EPI_BACKWARD>(la, grid_l, st, net->precision);
   la.in = dv1; la.out = dh + (nh - 1) * hs; la.act = sh + (nh - 1) * hs; la.IN = H / 2; la.OUT = H; la.mat_off = (unsigned)K.wv0t();
   la.kp_log = log2i(round_up64(H / 2)); la.layer = nh - 1; la.init_w = d_params + L.wp(); la.init_s = b.du;
-  launch_wide_layer<EPI_BACKWARD>(la, grid_l, st);
+  launch_wide_layer<EPI_BACKWARD>(la, grid_l, st, net->precision);
   la.init_w = nullptr; la.init_s = nullptr;
   for (int l = nh - 1; l >= 1; --l) {
     la.in = dh + l * hs; la.out = dh + (l - 1) * hs; la.act = sh + (l - 1) * hs; la.IN = H; la.OUT = H; la.mat_off = (unsigned)K.wt(l);
     la.kp_log = log2i(H); la.layer = l - 1;
-    launch_wide_layer<EPI_BACKWARD>(la, grid_l, st);
+    launch_wide_layer<EPI_BACKWARD>(la, grid_l, st, net->precision);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;

@@ -332,6 +332,31 @@ struct X3 {
   template <int R> static __device__ __forceinline__ void split(float x0, float x1, Frag& f) { split_pair2<R>(x0, x1, f); }
 };
 
+// bf16-mixed (PINN_PREC_BF16 on the wide nets): ONE bf16 part per operand, one MFMA per product, fp32 accumulation -- the
+// arithmetic of pinn_bf16_core.h on the slab machinery (the first of the three bf16 weight copies IS bf16(w), round-to-nearest)
+struct Frag1 {
+  u32x4 hi;
+};
+struct AFrag1 {
+  bf16x8 h;
+};
+struct B1 {
+  static constexpr int kCopies = 1;
+  static constexpr float kActScale = 1.0f, kAccScale = 1.0f;
+  using Frag = Frag1;
+  using AFrag = AFrag1;
+  using Pipe = PipeT<1>;
+  template <int MT> static __device__ __forceinline__ void load(AFrag& a, unsigned addr) { a.h = lds_read_b128<MT * 1024>(addr); }
+  template <int N> static __device__ __forceinline__ void wait(AFrag& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a.h) : "n"(N)); }
+  static __device__ __forceinline__ void mma(f32x4& acc, const AFrag& a, const Frag& b) {
+    acc = PINN_MFMA_BF16(a.h, __builtin_bit_cast(bf16x8, b.hi), acc);
+  }
+  template <int R> static __device__ __forceinline__ void split(float x0, float x1, Frag& f) {
+    const bf16x2 h = {(__bf16)x0, (__bf16)x1};
+    f.hi[R] = __builtin_bit_cast(unsigned, h);
+  }
+};
+
 // One tile pair.  vchunk(IC<c>): VALU chunk c (one per tile) of the next group's preparation; dma(IC<slot>): this
 // wave's LDS-DMA piece(s) of the next slab.  Order pinned: MFMAs of a tile, reads of the tile after next, chunk.
 // (Measured alternatives, all slower or equal: chunk free to mix with the MFMAs; sched_group_barrier 1 MFMA : 5 VALU;

@@ -3,6 +3,7 @@
 // dW = dpre^T . h over K = rows, both operands read straight from the fp32 stash ([T16][F][16]: 8 contiguous rows
 // of one feature per lane = one v_mfma_f32_32x32x16_bf16 fragment), split in registers into bf16 parts
 // x = hi + mid (+ lo), and multiplied as
+//     NS = 1:  hi.hi                                         (bf16-mixed: PINN_PREC_BF16 on the wide nets)
 //     NS = 2:  hi.hi + hi.mid + mid.hi                       (3 MFMAs per product)
 //     NS = 3:  ... + hi.lo + lo.hi + mid.mid                 (6 MFMAs, fp32-equivalent)
 // with fp32 accumulation.  NS = 2 drops terms of relative size 2^-16 per PRODUCT; they are zero-mean rounding
@@ -358,12 +359,13 @@ static int launch_d(const WgradArgs& a, int ns, hipStream_t st) {
   const size_t lds = (size_t)WI * WJ * 2 * (TI + TJ) * 2048;
   auto k3 = wgrad_d_kernel<TI, TJ, WI, WJ, 3>;
   auto k2 = wgrad_d_kernel<TI, TJ, WI, WJ, 2>;
+  auto k1 = wgrad_d_kernel<TI, TJ, WI, WJ, 1>;
+  auto k = ns == 3 ? k3 : (ns == 2 ? k2 : k1);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)(ns == 3 ? k3 : k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  if (ns == 3) hipLaunchKernelGGL(k3, grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL(k2, grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
   return PINN_OK;
 }
 
@@ -371,12 +373,14 @@ template <int TI, int TJ, int WI, int WJ>
 static void launch(const WgradArgs& a, int ns, hipStream_t st) {
   const dim3 grid(a.n_slices, a.OUT / (TI * 32 * WI), a.IN / (TJ * 32 * WJ));
   if (ns == 3) hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, 3>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, 2>), grid, dim3(256), 0, st, a);
+  else if (ns == 2) hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, 2>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, 1>), grid, dim3(256), 0, st, a);
 }
 
 }  // namespace x6
 
-// [OUT x IN] gradient with IN a multiple of 32 (every layer but the input one); ns = bf16 parts per operand (2 or 3)
+// [OUT x IN] gradient with IN a multiple of 32 (every layer but the input one); ns = bf16 parts per operand (3: x6; 2: the
+// opt-in three-product form; 1: bf16-mixed, one product -- wide nets under PINN_PREC_BF16)
 int dispatch_wgrad_x6(const WgradArgs& a, int ns, void* stream) {
   using namespace x6;
   hipStream_t st = (hipStream_t)stream;

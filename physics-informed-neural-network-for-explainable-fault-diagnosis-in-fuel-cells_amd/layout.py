@@ -42,7 +42,7 @@ def check_arch(layers):
         raise ValueError("all hidden layers must share one width (got %r)" % (layers,))
     if hid[0] not in (128, 256, 512, 1024, 2048):
         raise ValueError("hidden width must be 128 or 256 (register-resident MFMA chain) or 512 / 1024 / 2048 "
-                         "(layer-by-layer kernels, precision 'f32x6' only); got %d" % hid[0])
+                         "(layer-by-layer kernels, every precision but 'fp32'); got %d" % hid[0])
     if not (1 <= len(hid) <= 8):
         raise ValueError("1..8 hidden layers supported")
     return n_in, hid[0], len(hid)

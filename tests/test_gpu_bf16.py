@@ -20,7 +20,8 @@ def lib():
     return _lib.load()
 
 
-@pytest.mark.parametrize("H,nh,N,mode", [(256, 3, 1000, 0), (256, 3, 777, 1), (128, 3, 333, 1), (128, 1, 64, 1), (256, 5, 130, 1)])
+@pytest.mark.parametrize("H,nh,N,mode", [(256, 3, 1000, 0), (256, 3, 777, 1), (128, 3, 333, 1), (128, 1, 64, 1), (256, 5, 130, 1),
+                                         (512, 2, 300, 1), (1024, 4, 200, 1)])          # the last two: wide nets (pinn_wide.hip, scheme B1)
 def test_forward_bf16(lib, H, nh, N, mode):
     import hip_helpers as hh
     from pinn_amd import synth
@@ -71,7 +72,7 @@ def test_mc_dropout_bf16(lib):
     assert abs(np.mean(o[2]) / np.mean(eu) - 1) < 2e-2 and abs(np.mean(o[1]) / np.mean(au) - 1) < 2e-2
 
 
-@pytest.mark.parametrize("H,nh,N,mode", [(256, 3, 1000, 1), (128, 3, 333, 1), (256, 2, 129, 0), (128, 1, 64, 1)])
+@pytest.mark.parametrize("H,nh,N,mode", [(256, 3, 1000, 1), (128, 3, 333, 1), (256, 2, 129, 0), (128, 1, 64, 1), (512, 2, 300, 1), (1024, 4, 200, 1)])
 def test_train_grads_bf16(lib, H, nh, N, mode):
     """bf16-mixed training step: loss against the same-policy oracle (tight), gradients against the fp32
     reference arithmetic at the mixed-precision tolerance (5e-2 of each tensor's max: d pre-activations are rounded to bf16 before the K = rows contraction)."""

@@ -304,7 +304,7 @@ def test_wide_model_surface():
     pm, au, eu = pinn_amd.get_MC_samples(m, ds[0], ds[4], mc_times=4, dropout=0.4)
     assert np.all(np.isfinite(pm)) and np.all(au > 0) and np.all(eu > 0)
     with pytest.raises(Exception):
-        m.dnn.set_precision("fp32"); m.predict(ds[0], ds[4])          # wide nets: x6 arithmetic only
+        m.dnn.set_precision("fp32"); m.predict(ds[0], ds[4])          # wide nets: split-operand or bf16-mixed arithmetic only
 
 
 def test_forward_wide_multi_chunk(lib):

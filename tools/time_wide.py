@@ -6,11 +6,13 @@ import _common as hh
 from _common import _lib, lib
 H, nh = 1024, 4
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+PREC = int(sys.argv[2]) if len(sys.argv) > 2 else 2          # 2: f32x6, 1: bf16-mixed
 M = 8 * H + (nh - 1) * H * H + H + H * H // 2 + H * H // 8 + H // 4
 fp = hh.random_params(H, nh)
 x = torch.rand(N, 8, device=hh.dev()); y = torch.rand(N, device=hh.dev())
 drop = hh.dropout_struct(1, [0.2] * (nh + 1), seed=1, stream_id=2)
-net = hh.make_net(H, nh, 2)
+net = hh.make_net(H, nh, PREC)
+print("precision", PREC)
 def ev(fn, reps):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
