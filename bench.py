@@ -17,12 +17,14 @@ One timed "step" advances EVERY trainer of the reference once over those rows:
 value = rows of all ranks * steps / max-over-ranks wall time (weak scaling: rows per GPU fixed).
 
 Arithmetic (--precision, default f32x6 = the library default): fp32 in, fp32 out, fp32 accumulation;
-the matrix products run on the 16-bit matrix cores with split operands -- forward passes: two fp16
-parts (power-of-two scaled into fp16's range), three cross products; backward chain and weight
-gradients: three bf16 parts (hi + mid + lo = the fp32 value exactly), six cross products -- the
-accuracy of an fp32 matmul (same parity tests and tolerances as the exact-fp32 kernels).  The
-exact-fp32 kernels (v_mfma_f32_*_f32), the opt-in bf16-mixed ones and the opt-in f32x6g3 variant
-(three products everywhere) are measured beside it unless --only.
+the matrix products run on the 16-bit matrix cores with split operands: two fp16 parts per operand
+(exact power-of-two scales bring them into fp16's range: constants in the forward passes, per row in
+the backward chain, one per call -- from the largest d pre-activation -- in the weight gradients),
+three cross products -- the accuracy of an fp32 matmul (same parity tests and tolerances as the
+exact-fp32 kernels; gradient tensors as close to a float64 autograd as torch's own fp32 autograd).
+The exact-fp32 kernels (v_mfma_f32_*_f32), the opt-in bf16-mixed ones and the f32x6g6 variant
+(gradients from three bf16 parts, six products: round 2's first default) are measured beside it
+unless --only.
 
 Extra legs reported in the same JSON line (rank 0):
    mc_dropout   : get_MC_samples-equivalent launch (1 eval + T stochastic passes, on-chip reduce)
@@ -63,17 +65,16 @@ FWD_FLOP_PER_ROW = 2 * M_MAC
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 # Matrix instructions executed per algorithmic multiply-add ("products"), per phase -- the split-operand schemes of
-# pinn_x6_core.h: X3 = two fp16 parts, 3 products (forward passes); x6 = three bf16 parts, 6 products (backward chain,
-# weight gradients); the peak an algorithmic FLOP can be priced against is the dense 16-bit MFMA peak / products.
+# pinn_x6_core.h: X3 = two fp16 parts, 3 products; x6 = three bf16 parts, 6 products; the peak an algorithmic FLOP can be
+# priced against is the dense 16-bit MFMA peak / products.
 # per precision: (dtype string, chain kernel name, forward kernel name, products forward, products backward, products wgrad,
 #                 peak of one executed product in TFLOP/s)
 PRECISIONS = {
-    "f32x6": ("f32 (split-operand matrix products, f32 accumulate, fp32-matmul accuracy: forward 2 fp16 parts / 3 MFMAs, "
-              "backward + weight gradients 3 bf16 parts / 6 MFMAs)",
-              "train_fwd_x3_kernel<256> + train_bwd_kernel<X6,256>", "mlp_x6_kernel<256,MC> (scheme X3)", 3, 6, 6, PEAK_BF16_MFMA_TFLOPS),
-    "f32x6g3": ("f32 (as f32x6; backward chain in 2 fp16 parts / 3 MFMAs on row-normalised gradients, weight gradients from 2 bf16 "
-                "parts / 3 MFMAs: ~5e-6 relative gradient error)",
-                "train_fwd_x3_kernel<256> + train_bwd_kernel<X3,256>", "mlp_x6_kernel<256,MC> (scheme X3)", 3, 3, 3, PEAK_BF16_MFMA_TFLOPS),
+    "f32x6": ("f32 (split-operand matrix products on the 16-bit matrix cores, f32 accumulate, fp32-matmul accuracy: 2 fp16 parts / "
+              "3 MFMAs per product in forward, backward and weight gradients)",
+              "train_fwd_x3_kernel<256> + train_bwd_kernel<X3,256>", "mlp_x6_kernel<256,MC> (scheme X3)", 3, 3, 3, PEAK_BF16_MFMA_TFLOPS),
+    "f32x6g6": ("f32 (as f32x6 with the gradients -- backward chain, weight gradients -- from 3 bf16 parts / 6 MFMAs per product)",
+                "train_fwd_x3_kernel<256> + train_bwd_kernel<X6,256>", "mlp_x6_kernel<256,MC> (scheme X3)", 3, 6, 6, PEAK_BF16_MFMA_TFLOPS),
     "fp32": ("f32 (exact: v_mfma_f32_*_f32)", "train_chain_kernel<256>", "mlp_kernel<256,MC>", 1, 1, 1, PEAK_FP32_MFMA_TFLOPS),
     "bf16": ("bf16 MFMA inputs, f32 accumulate/activations/loss/master weights (parity rtol 2e-2)",
              "train_chain_bf16_kernel<256>", "mlp_bf16_kernel<256,MC>", 1, 1, 1, PEAK_BF16_MFMA_TFLOPS),
@@ -555,7 +556,7 @@ def main():
     if rows == 1_000_000 and pmc:
         try:
             # one entry per kernel of the chain ("train_fwd_x3_kernel<256> + train_bwd_kernel<X6,256>": two launches per step)
-            keys = [part.strip().split("<")[0] + "<" + ("pinn::x6::" + part.split("<")[1].split(",")[0] if "bwd" in part else "")
+            keys = [part.strip().split("<")[0] + "<" + ("pinn::x6::" + part.split("<")[1].split(",")[0] + "," if "bwd" in part else "")
                     for part in head["roofline"]["kernel"].split("+")]
             table = json.load(open(pmc))
             ks = [[v for n, v in table.items() if key in n][0] for key in keys]
@@ -570,7 +571,7 @@ def main():
 
     # ------------------------------------------------------------------ extra legs: the same measurement in the other precisions
     if not args.only:
-        extras = [("exact_fp32", "fp32")] + ([] if args.no_bf16 else [("bf16_mixed", "bf16")]) + [("f32x6_g3_opt_in", "f32x6g3")]
+        extras = [("exact_fp32", "fp32")] + ([] if args.no_bf16 else [("bf16_mixed", "bf16")]) + [("f32x6_g6", "f32x6g6")]
         for name, prec in extras:
             if prec == args.precision:
                 continue

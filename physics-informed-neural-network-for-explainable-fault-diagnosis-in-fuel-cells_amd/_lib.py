@@ -32,7 +32,7 @@ class Affine(ctypes.Structure):
                 ("y_scale", ctypes.c_double), ("vn_scale", c_float), ("vn_min", c_float)]
 
 
-PREC_FP32, PREC_BF16, PREC_F32X6, PREC_F32X6_G3 = 0, 1, 2, 3
+PREC_FP32, PREC_BF16, PREC_F32X6, PREC_F32X6_G6 = 0, 1, 2, 3
 STAGE_RUN_MAX_ROWS, STAGE_LOG_FLOATS = 65536, 64
 
 

@@ -564,6 +564,6 @@ extern "C" size_t pinn_packed_bytes(const pinn_net_t* net) {
   if (wide) return net->precision != PINN_PREC_FP32 ? (size_t)K.total() * 2 * 5 + pinn::wide_scratch_floats(net->hidden) * 4 : 0;
   if (net->precision == PINN_PREC_BF16) return (size_t)K.total() * 2;
   // three bf16 copies (hi, mid, lo: backward pass, weight gradients) + two fp16 copies of the forward matrices (scheme X3)
-  if (net->precision == PINN_PREC_F32X6 || net->precision == PINN_PREC_F32X6_G3) return (size_t)K.total() * 2 * 5;
+  if (net->precision == PINN_PREC_F32X6 || net->precision == PINN_PREC_F32X6_G6) return (size_t)K.total() * 2 * 5;
   return 0;
 }

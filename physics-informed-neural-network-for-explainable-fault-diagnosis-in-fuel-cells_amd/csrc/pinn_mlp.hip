@@ -104,7 +104,7 @@ static int check_net(const pinn_net_t* net) {
   const bool wide = net->hidden == 512 || net->hidden == 1024 || net->hidden == 2048;    // layer-by-layer kernels (pinn_wide.hip)
   if (net->hidden != 128 && net->hidden != 256 && !wide) return PINN_E_ARCH;
   if (net->n_hidden < 1 || net->n_hidden > 8) return PINN_E_ARCH;
-  if (net->precision < PINN_PREC_FP32 || net->precision > PINN_PREC_F32X6_G3) return PINN_E_ARG;
+  if (net->precision < PINN_PREC_FP32 || net->precision > PINN_PREC_F32X6_G6) return PINN_E_ARG;
   if (wide && net->precision == PINN_PREC_FP32) return PINN_E_ARCH;                      // split-operand or bf16 arithmetic only
   if (net->precision != PINN_PREC_FP32 && !net->d_packed) return PINN_E_ARG;
   return PINN_OK;

@@ -484,6 +484,8 @@ struct TrainBuffers {
   float* slabs;
   long long t16;
   int n_slices;
+  unsigned* amax;     // PINN_PREC_F32X6 (fused nets): bits of max |d pre-activation| over the whole call (non-negative floats order like
+                      // unsigned integers: atomicMax, order-independent), the fp16 weight-gradient kernels' common scale
 };
 
 // kernel arguments of the forward / MC-dropout kernels (fp32 and bf16 variants)

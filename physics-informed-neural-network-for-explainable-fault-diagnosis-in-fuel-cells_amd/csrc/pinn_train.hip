@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
 struct Workspace {
   long long t16;
   size_t off_stash_h, off_stash_v1, off_stash_v2, off_dpre_h, off_dpre_v1, off_dpre_v2, off_keep, off_du, off_dz, off_loss,
-      off_slabs;
+      off_amax, off_slabs;
   int n_slices;
   size_t total;
 };
@@ -490,6 +490,7 @@ static Workspace plan_workspace(const pinn_net_t* net, long long n_rows) {
   w.off_du = take((size_t)w.t16 * 16 * 4);
   w.off_dz = take((size_t)w.t16 * 16 * 4);
   w.off_loss = take((size_t)1024 * kLossTerms * 8);
+  w.off_amax = take(256);
   const long long t32 = (w.t16 + 1) / 2;
   w.n_slices = (int)(t32 < kMaxSlices ? (t32 < 1 ? 1 : t32) : kMaxSlices);
   ParamLayout L{(int)H, (int)nh};
@@ -504,7 +505,7 @@ static int check_net_t(const pinn_net_t* net) {
   const bool wide = net->hidden == 512 || net->hidden == 1024 || net->hidden == 2048;    // layer-by-layer kernels (pinn_wide.hip)
   if (net->hidden != 128 && net->hidden != 256 && !wide) return PINN_E_ARCH;
   if (net->n_hidden < 1 || net->n_hidden > 8) return PINN_E_ARCH;
-  if (net->precision < PINN_PREC_FP32 || net->precision > PINN_PREC_F32X6_G3) return PINN_E_ARG;
+  if (net->precision < PINN_PREC_FP32 || net->precision > PINN_PREC_F32X6_G6) return PINN_E_ARG;
   if (wide && net->precision == PINN_PREC_FP32) return PINN_E_ARCH;
   if (net->precision != PINN_PREC_FP32 && !net->d_packed) return PINN_E_ARG;
   return PINN_OK;
@@ -639,6 +640,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
       b.dpre_h = a.dpre_h; b.dpre_v1 = a.dpre_v1; b.dpre_v2 = a.dpre_v2;
       b.keep = a.keep; b.du = a.du; b.dz = a.dz; b.loss_part = a.loss_part;
       b.slabs = (float*)(base + w.off_slabs); b.t16 = w.t16; b.n_slices = w.n_slices;
+      b.amax = (unsigned*)(base + w.off_amax);
       rc = H > 256 ? launch_train_chain_wide(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, &grid, stream)
                    : launch_train_chain_x6(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, which, &grid, stream);
       if (rc) return rc;
@@ -666,13 +668,15 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
   if (phases & PINN_PHASE_WGRAD) {
     WgradArgs g{};
     g.x = d_x; g.n_rows = n_rows; g.t16 = w.t16; g.n_slices = w.n_slices; g.slab_stride = tot;
+    g.amax = (const unsigned*)(base + w.off_amax);
     // layer 0: dW0 = dpre_0 x^T
     g.P = a.dpre_h; g.Q = nullptr; g.OUT = H; g.IN = 8; g.dW = slabs + L.w0(); g.db = slabs + L.b0();
     g.s1 = nullptr; g.dvq = nullptr; g.s2 = nullptr; g.R = nullptr; g.dvr = nullptr;
     if ((rc = dispatch_wgrad(g, st))) return rc;
     // every layer but the input one: split-bf16 products on the matrix cores for PINN_PREC_F32X6
-    // bf16 parts per operand (0: exact fp32 kernels; 1: bf16-mixed on the wide nets)
-    const int ns = net->precision == PINN_PREC_F32X6 ? 3 : (net->precision == PINN_PREC_F32X6_G3 ? 2 : (net->precision == PINN_PREC_BF16 ? 1 : 0));
+    // operand split of the weight-gradient kernels: 0 = exact fp32 kernels; 3 = three bf16 parts, six products (x6); 4 = two fp16
+    // parts under the common scale the X3 backward chain measured (PINN_PREC_F32X6 on the fused nets); 1 = bf16-mixed (wide nets)
+    const int ns = net->precision == PINN_PREC_F32X6 ? (H <= 256 ? 4 : 3) : (net->precision == PINN_PREC_F32X6_G6 ? 3 : (net->precision == PINN_PREC_BF16 ? 1 : 0));
     auto wgrad = [&](const WgradArgs& wa) { return ns ? dispatch_wgrad_x6(wa, ns, stream) : dispatch_wgrad(wa, st); };
     for (int l = 1; l < nh; ++l) {
       g.P = a.dpre_h + l * hs; g.Q = a.stash_h + (l - 1) * hs; g.OUT = H; g.IN = H; g.dW = slabs + L.w(l); g.db = slabs + L.b(l);

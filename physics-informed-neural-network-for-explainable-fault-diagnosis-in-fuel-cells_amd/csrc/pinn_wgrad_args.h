@@ -17,6 +17,7 @@ struct WgradArgs {
   float* db;                // slab of slice 0: [OUT]
   const float* s1; float* dvq;                    // optional: dvq[j] = sum_rows s1[row] Q[j][row]
   const float* s2; const float* R; float* dvr;    // optional: dvr[i] = sum_rows s2[row] R[i][row]
+  const unsigned* amax;     // fp16 scheme only: bits of max |P| over the call (TrainBuffers::amax)
 };
 
 

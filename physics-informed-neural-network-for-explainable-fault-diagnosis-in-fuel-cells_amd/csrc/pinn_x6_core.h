@@ -737,7 +737,7 @@ struct StashRing {
 // its normalisation (scheme X3, see backward_pass); the stash gets them back in true units: x unnorm.
 template <typename S, int k>
 __device__ __forceinline__ void bprep_micro(typename S::Frag& out, f32x4& d0, f32x4& d1, const StashRing& ring, int buf, float* dsp, float gscale,
-                                            float inv_scale, float unnorm) {
+                                            float inv_scale, float unnorm, float& mx) {
   if constexpr (k >= 2 && k < 6) {
     constexpr int r = k - 2;
     const float h0 = ring.read(buf, 0, r), h1 = ring.read(buf, 1, r);
@@ -751,6 +751,7 @@ __device__ __forceinline__ void bprep_micro(typename S::Frag& out, f32x4& d0, f3
     for (int r = 0; r < 4; ++r) {
       PINN_STASH_ST(dsp + r * 16, S::kActScale != 1.0f ? d0[r] * unnorm : d0[r]);
       PINN_STASH_ST(dsp + (16 + r) * 16, S::kActScale != 1.0f ? d1[r] * unnorm : d1[r]);
+      if constexpr (S::kActScale != 1.0f) mx = fmaxf(fmaxf(mx, fabsf(d0[r])), fabsf(d1[r]));      // (normalised units; v_max3_f32)
     }
   }
 }
@@ -764,7 +765,7 @@ __device__ __forceinline__ void bprep_micro(typename S::Frag& out, f32x4& d0, f3
 // the weights' row sums, far inside fp16's range), and what goes to the stash is multiplied by 1 / norm again (exact).
 template <typename S, int H, int WAVES = 8>
 __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLayout& L, typename S::Pipe& pipe, const DropDev& d, int mode,
-                                              const StashX& sx, const StashRing& ring, int lane, float du, float dz) {
+                                              const StashX& sx, const StashRing& ring, int lane, float du, float dz, float& amax) {
   constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32, NC = S::kCopies;
   constexpr int NG1 = (H / 4) / 32 > 0 ? (H / 4) / 32 : 1;                 // K-groups of Wv1^T (K = H/4)
   constexpr int KPW = clog2(H), KPT0 = clog2((H / 2 + 63) & ~63), KPT1 = clog2((H / 4 + 63) & ~63);
@@ -787,6 +788,7 @@ __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLa
 
   // per-row normalisation (X3): norm = 2^(4 - e) with max(|du|, |dz|) = m 2^e, m in [0.5, 1)
   float unnorm = 1.0f;
+  float mx = 0.0f;        // X3: max |d pre-activation| this lane stashes for this tile, in the row's normalised units
   if constexpr (S::kActScale != 1.0f) {
     int e = 0;
     const float mx = fmaxf(fabsf(du), fabsf(dz));
@@ -815,6 +817,7 @@ __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLa
       for (int r = 0; r < 4; ++r) {
         v2[t][r] = w[r] * dz * (1.0f - v2[t][r] * v2[t][r]);
         true_units[r] = v2[t][r] * unnorm;
+        if constexpr (S::kActScale != 1.0f) mx = fmaxf(mx, fabsf(v2[t][r]));
       }
       store_block(sp, t, true_units);
     }
@@ -844,7 +847,7 @@ __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLa
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // block 0 was requested at the top of this pass
             fetch_block(1);
           }
-          bprep_micro<S, k>(out, dpv1[0], dpv1[1], ring, 0, dsp, gscale, inv_scale, unnorm);
+          bprep_micro<S, k>(out, dpv1[0], dpv1[1], ring, 0, dsp, gscale, inv_scale, unnorm, mx);
         });
   }
 
@@ -866,13 +869,13 @@ __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLa
         [&](auto gc, auto kc, Frag& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
           if constexpr (k == 0) fetch_block(g + 1);
-          bprep_micro<S, k>(out, dpv1[2 * g], dpv1[2 * g + 1], ring, g & 1, dsp + 32 * g * 16, gscale, inv_scale, unnorm);
+          bprep_micro<S, k>(out, dpv1[2 * g], dpv1[2 * g + 1], ring, g & 1, dsp + 32 * g * 16, gscale, inv_scale, unnorm, mx);
         },
         [&](auto kc, Frag& out) {
           constexpr int k = decltype(kc)::value;
           if (nh > 1) {
             if constexpr (k == 0) fetch_block(NP / 2 + 1);
-            bprep_micro<S, k>(out, dh[0], dh[1], ring, (NP / 2) & 1, dsp_o, gscale_o, inv_scale_o, unnorm);
+            bprep_micro<S, k>(out, dh[0], dh[1], ring, (NP / 2) & 1, dsp_o, gscale_o, inv_scale_o, unnorm, mx);
           }
         },
         nh > 1);
@@ -894,13 +897,13 @@ __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLa
         [&](auto gc, auto kc, Frag& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
           if constexpr (k == 0) fetch_block(base + g + 1);
-          bprep_micro<S, k>(out, dh[2 * g], dh[2 * g + 1], ring, (base + g) & 1, dsp + 32 * g * 16, gscale, inv_scale, unnorm);
+          bprep_micro<S, k>(out, dh[2 * g], dh[2 * g + 1], ring, (base + g) & 1, dsp + 32 * g * 16, gscale, inv_scale, unnorm, mx);
         },
         [&](auto kc, Frag& out) {
           constexpr int k = decltype(kc)::value;
           if (l > 1) {
             if constexpr (k == 0) fetch_block(base + NP + 1);
-            bprep_micro<S, k>(out, acc[0], acc[1], ring, (base + NP) & 1, dsp_o, gscale_o, inv_scale_o, unnorm);
+            bprep_micro<S, k>(out, acc[0], acc[1], ring, (base + NP) & 1, dsp_o, gscale_o, inv_scale_o, unnorm, mx);
           }
         },
         l > 1);
@@ -924,10 +927,12 @@ __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLa
         const float a0 = hl[t][r] * inv_scale;
         const float g0 = dh[t][r] * (gscale * (1.0f - a0 * a0));
         dh[t][r] = hl[t][r] != 0.0f ? g0 : 0.0f;
+        if constexpr (S::kActScale != 1.0f) amax = fmaxf(amax, fabsf(dh[t][r]));      // (already in true units)
       }
       store_block(dsp, t, dh[t]);
     }
   }
+  if constexpr (S::kActScale != 1.0f) amax = fmaxf(amax, mx * unnorm);
 }
 
 }  // namespace x6

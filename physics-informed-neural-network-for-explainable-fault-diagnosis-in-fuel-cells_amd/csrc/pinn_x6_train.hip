@@ -113,11 +113,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_fwd_x3_kernel(Tra
 }
 
 // backward chain of every row tile: d pre-activations of all layers to the stash, on the transposed copies.
-// S = X6 (PINN_PREC_F32X6): three bf16 parts -- every element of a gradient keeps its own 24 significant bits, which is
-// what Adam's division by sqrt(v) needs of the small ones too (3-step golden trajectory: 0.09 of the tolerance band from
-// float64; the reference's own fp32: 0.41).  S = X3 (PINN_PREC_F32X6_G3, opt-in): two fp16 parts on per-row-normalised
-// gradients, half the MFMAs (chain 3.7 -> 3.3 ms at 1e6 rows) -- elements far below their row's largest gradient lose
-// relative precision (fp16's 5-bit exponent), 0.91 of the band: inside it against float64, 1.3 x against the reference.
+// S = X3 (PINN_PREC_F32X6): two fp16 parts of per-row-normalised gradients, three MFMAs per product (backward_pass); it also
+// records the call's largest |d pre-activation| (TrainBuffers::amax), the common scale of the fp16 weight-gradient kernels.
+// S = X6 (PINN_PREC_F32X6_G6): three bf16 parts of every operand, six MFMAs.  Against a float64 autograd both leave the
+// gradient tensors as close as torch's own fp32 autograd does (rms error 5e-8 .. 1.2e-7 of a tensor's rms); the
+// golden 3-step Adam trajectory passes with either.
 template <typename S, int H, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_bwd_kernel(TrainArgsX a, const __bf16* packed) {
   constexpr int kThreadsX = WAVES * 64, kTileRowsX = WAVES * 16;
@@ -140,12 +140,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_bwd_kernel(TrainA
   const int lane = threadIdx.x & 63, wave = pipe.wave;
   const StashRing ring{ring_lds + wave * 4096, lane};
   const long long n_tiles = (a.n_rows + 127) / 128 * (128 / kTileRowsX);
+  float amax = 0.0f;       // X3: max |d pre-activation| this lane has stashed (true units)
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long t16 = tile * WAVES + wave;
     const StashX sx{(float*)a.b.stash_h, (float*)a.b.stash_v1, (float*)a.b.stash_v2, (float*)a.b.dpre_h, (float*)a.b.dpre_v1, (float*)a.b.dpre_v2,
                     a.b.t16, t16};
     const float du = a.b.du[t16 * 16 + (lane & 15)], dz = a.b.dz[t16 * 16 + (lane & 15)];
-    backward_pass<S, H, WAVES>(small, L, pipe, a.drop, a.drop.mode, sx, ring, lane, du, dz);
+    backward_pass<S, H, WAVES>(small, L, pipe, a.drop, a.drop.mode, sx, ring, lane, du, dz, amax);
+  }
+  if constexpr (S::kActScale != 1.0f) {
+    // the call's common scale for the fp16 weight-gradient kernels: one atomicMax per wave on the float's bits (non-negative
+    // floats order like unsigned integers, so the result does not depend on the order of the waves; fmaxf drops NaNs -- a NaN
+    // gradient still reaches the stash and, through the operands, the weight gradients)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    if (lane == 0) atomicMax(a.b.amax, __float_as_uint(amax));
   }
 }
 
@@ -176,8 +185,12 @@ int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const fl
   *grid_out = grid;
   const __bf16* packed = (const __bf16*)net->d_packed;
   const bool bits = drop.mode == PINN_DROP_BITS;
-  const bool fast_bwd = net->precision == PINN_PREC_F32X6_G3;        // opt-in: the backward chain in scheme X3 too
+  const bool fast_bwd = net->precision == PINN_PREC_F32X6;           // backward chain in scheme X3 (PINN_PREC_F32X6_G6: x6)
   const bool run_fwd = which & 1u, fwd_only = !(which & 2u);
+  if (fast_bwd && !fwd_only) {
+    hipError_t em = hipMemsetAsync(b.amax, 0, sizeof(unsigned), st);
+    if (em != hipSuccess) return (int)em;
+  }
 #define PINN_LAUNCH_T(HH, BB)                                                                                                   \
   do {                                                                                                                          \
     if (small_n) {                                                                                                              \

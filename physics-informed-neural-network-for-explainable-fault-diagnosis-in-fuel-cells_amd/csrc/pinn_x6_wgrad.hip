@@ -1,14 +1,12 @@
-// pinn_x6_wgrad.hip -- weight gradients on the bf16 matrix cores for PINN_PREC_F32X6.
+// pinn_x6_wgrad.hip -- weight gradients on the 16-bit matrix cores (every precision but exact fp32).
 //
 // dW = dpre^T . h over K = rows, both operands read straight from the fp32 stash ([T16][F][16]: 8 contiguous rows
-// of one feature per lane = one v_mfma_f32_32x32x16_bf16 fragment), split in registers into bf16 parts
-// x = hi + mid (+ lo), and multiplied as
-//     NS = 1:  hi.hi                                         (bf16-mixed: PINN_PREC_BF16 on the wide nets)
-//     NS = 2:  hi.hi + hi.mid + mid.hi                       (3 MFMAs per product)
-//     NS = 3:  ... + hi.lo + lo.hi + mid.mid                 (6 MFMAs, fp32-equivalent)
-// with fp32 accumulation.  NS = 2 drops terms of relative size 2^-16 per PRODUCT; they are zero-mean rounding
-// residues and the gradient is a sum over all rows, so the tensors come out ~5e-6 of their largest element from the
-// float64 result (torch's fp32 matmul: 3e-7; the parity tolerance on gradients: 2e-4) at half the NS = 3 cost.
+// of one feature per lane = one 32x32x16 MFMA fragment), split in registers, fp32 accumulation:
+//     NS = 4 (kF16S): two fp16 parts under a common power-of-two scale, three MFMAs per product -- see split8_p
+//                     (PINN_PREC_F32X6 on the fused nets)
+//     NS = 3:  three bf16 parts x = hi + mid + lo (exact), six MFMAs: hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid
+//                     (PINN_PREC_F32X6_G6; PINN_PREC_F32X6 on the wide nets)
+//     NS = 1:  hi.hi  (bf16-mixed: PINN_PREC_BF16 on the wide nets)
 // Same slices / slabs / bias and vector-head sums as wgrad_kernel (pinn_train.hip); layer 0 (IN = 8) stays there.
 #include <cstdlib>
 #include "pinn_x6_core.h"
@@ -61,6 +59,72 @@ __device__ __forceinline__ Parts<NS> split8(const f32x4& v0, const f32x4& v1) {
   return o;
 }
 
+// ---- NS = kF16S: two fp16 parts, three products (v_mfma_f32_32x32x16_f16), 22 significant bits per operand.
+// d pre-activations span many orders of magnitude (1 / N of the loss in front, per-row precisions): G = a power of two that
+// puts the call's largest |d pre| (TrainBuffers::amax, measured by the X3 backward chain) in [2^14, 2^15), and the low part is
+// stored SCALED, lo' = fp16((G x - hi) 2^11), so that it is a normal fp16 wherever hi is (down to 2^-29 of the largest
+// element; below that the error is absolute, 2^-36 of it).  Its product needs the other operand's high part times 2^-11:
+//     G x = hi + lo' / 2048,   8 h = hh + hl,   hs = fp16(hh / 2048)   ->   8 G x h ~ hi hh + hi hl + lo' hs
+// (dropped: lo' hl / 2048, 2^-22 of the product).  Activations (|h| <= 1.67 / (1 - p)) carry the x 8 of scheme X3.
+constexpr int kF16S = 4;
+#define PINN_MFMA32_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+struct PartsP { u32x4 hi, lo; };
+struct PartsQ { u32x4 hi, lo, hs; };
+__device__ __forceinline__ unsigned pack_f16(float x0, float x1) {
+  const f16x2 h = {(_Float16)x0, (_Float16)x1};
+  unsigned p = __builtin_bit_cast(unsigned, h);
+  asm volatile("" : "+v"(p));
+  return p;
+}
+__device__ __forceinline__ PartsP split8_p(const f32x4& v0, const f32x4& v1, float g) {
+  PartsP o;
+  const f32x2 x[4] = {{v0[0], v0[1]}, {v0[2], v0[3]}, {v1[0], v1[1]}, {v1[2], v1[3]}};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2 xg = x[q] * g;
+    const unsigned hp = pack_f16(xg[0], xg[1]);
+    const f16x2 h = __builtin_bit_cast(f16x2, hp);
+    const f32x2 hf = {(float)h[0], (float)h[1]};
+    const f32x2 r = (xg - hf) * 2048.0f;               // exact: the residual of a rounding, times a power of two
+    o.hi[q] = hp;
+    o.lo[q] = pack_f16(r[0], r[1]);
+  }
+  return o;
+}
+__device__ __forceinline__ PartsQ split8_q(const f32x4& v0, const f32x4& v1) {
+  PartsQ o;
+  const f32x2 x[4] = {{v0[0], v0[1]}, {v0[2], v0[3]}, {v1[0], v1[1]}, {v1[2], v1[3]}};
+  const f16x2 k = {(_Float16)0x1p-11f, (_Float16)0x1p-11f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2 x8 = x[q] * 8.0f;
+    const unsigned hp = pack_f16(x8[0], x8[1]);
+    const f16x2 h = __builtin_bit_cast(f16x2, hp);
+    const f32x2 hf = {(float)h[0], (float)h[1]};
+    const f32x2 r = x8 - hf;
+    o.hi[q] = hp;
+    o.lo[q] = pack_f16(r[0], r[1]);
+    o.hs[q] = __builtin_bit_cast(unsigned, h * k);    // v_pk_mul_f16
+  }
+  return o;
+}
+// G and 1 / (8 G) from the call's largest |d pre-activation| (bits in *amax); 1 where it is zero or not finite
+struct GScale { float g, inv; };
+__device__ __forceinline__ GScale g_scale(const unsigned* amax) {
+  const float am = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(*amax));
+  int e = 0;
+  (void)frexpf(am, &e);
+  const bool ok = am > 0.0f && am < __builtin_inff();
+  e = ok ? (e < -100 ? -100 : e) : 15;
+  return GScale{ldexpf(1.0f, 15 - e), ldexpf(1.0f, e - 18)};
+}
+// the three products of one block, smallest first
+__device__ __forceinline__ void mma_f16s(f32x16& acc, const PartsP& pa, const PartsQ& pb) {
+  acc = PINN_MFMA32_F16(__builtin_bit_cast(f16x8, pa.lo), __builtin_bit_cast(f16x8, pb.hs), acc);
+  acc = PINN_MFMA32_F16(__builtin_bit_cast(f16x8, pa.hi), __builtin_bit_cast(f16x8, pb.lo), acc);
+  acc = PINN_MFMA32_F16(__builtin_bit_cast(f16x8, pa.hi), __builtin_bit_cast(f16x8, pb.hi), acc);
+}
+
 template <int TI, int TJ>
 struct Raw {
   f32x4 a[TI][2], b[TJ][2];
@@ -90,6 +154,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
   // blockIdx.y / z: which [32 TI WI] x [32 TJ WJ] block of a larger gradient this workgroup computes
   const int i0 = blockIdx.y * (TI * 32 * WI) + wi * TI * 32, j0 = blockIdx.z * (TJ * 32 * WJ) + wj * TJ * 32;
   const bool row_sums = wj == 0 && blockIdx.z == 0, col_sums = wi == 0 && blockIdx.y == 0;
+  GScale gs{1.0f, 1.0f};
+  if constexpr (NS == kF16S) gs = g_scale(a.amax);
 
   f32x16 acc[TI][TJ];
 #pragma unroll
@@ -134,21 +200,35 @@ __global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
     }
   };
   auto tile = [&](const Raw<TI, TJ>& cur, const Side& sd, long long t) {
-    Parts<NS> pa[TI], pb[TJ];
+    if constexpr (NS == kF16S) {
+      PartsP pa[TI];
+      PartsQ pb[TJ];
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti) pa[ti] = split8<NS>(cur.a[ti][0], cur.a[ti][1]);
+      for (int ti = 0; ti < TI; ++ti) pa[ti] = split8_p(cur.a[ti][0], cur.a[ti][1], gs.g);
 #pragma unroll
-    for (int tj = 0; tj < TJ; ++tj) pb[tj] = split8<NS>(cur.b[tj][0], cur.b[tj][1]);
-    // products (sa, sb) with sa + sb < NS, smallest first
+      for (int tj = 0; tj < TJ; ++tj) pb[tj] = split8_q(cur.b[tj][0], cur.b[tj][1]);
 #pragma unroll
-    for (int tot = NS - 1; tot >= 0; --tot)
+      for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-      for (int sa = 0; sa <= tot; ++sa)
+        for (int tj = 0; tj < TJ; ++tj) mma_f16s(acc[ti][tj], pa[ti], pb[tj]);
+    } else {
+      constexpr int NP = NS == kF16S ? 1 : NS;
+      Parts<NP> pa[TI], pb[TJ];
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti)
+      for (int ti = 0; ti < TI; ++ti) pa[ti] = split8<NP>(cur.a[ti][0], cur.a[ti][1]);
 #pragma unroll
-          for (int tj = 0; tj < TJ; ++tj)
-            acc[ti][tj] = PINN_MFMA32_BF16(__builtin_bit_cast(bf16x8, pa[ti].p[sa]), __builtin_bit_cast(bf16x8, pb[tj].p[tot - sa]), acc[ti][tj]);
+      for (int tj = 0; tj < TJ; ++tj) pb[tj] = split8<NP>(cur.b[tj][0], cur.b[tj][1]);
+      // products (sa, sb) with sa + sb < NS, smallest first
+#pragma unroll
+      for (int tot = NP - 1; tot >= 0; --tot)
+#pragma unroll
+        for (int sa = 0; sa <= tot; ++sa)
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TJ; ++tj)
+              acc[ti][tj] = PINN_MFMA32_BF16(__builtin_bit_cast(bf16x8, pa[ti].p[sa]), __builtin_bit_cast(bf16x8, pb[tj].p[tot - sa]), acc[ti][tj]);
+    }
     if (row_sums) {
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti)
@@ -210,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = i0 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        a.dW[so + (long long)row * a.IN + col] = acc[ti][tj][r];
+        a.dW[so + (long long)row * a.IN + col] = NS == kF16S ? acc[ti][tj][r] * gs.inv : acc[ti][tj][r];
       }
     }
   if (row_sums) {
@@ -250,6 +330,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_d_kernel(WgradArgs a) {
   const int hh = lane >> 5, i = lane & 31;
   const int i0 = blockIdx.y * (TI * 32 * WI) + wi * TI * 32, j0 = blockIdx.z * (TJ * 32 * WJ) + wj * TJ * 32;
   const bool row_sums = wj == 0 && blockIdx.z == 0;
+  GScale gs{1.0f, 1.0f};
+  if constexpr (NS == kF16S) gs = g_scale(a.amax);
 
   f32x16 acc[TI][TJ];
 #pragma unroll
@@ -307,20 +389,34 @@ __global__ __launch_bounds__(256, 1) void wgrad_d_kernel(WgradArgs a) {
       fetch(clampt(t + 2), s0);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kFrags) : "memory");
       read(nxt, s0 ^ 1);
-      Parts<NS> pa[TI], pb[TJ];
+      if constexpr (NS == kF16S) {
+        PartsP pa[TI];
+        PartsQ pb[TJ];
 #pragma unroll
-      for (int ti = 0; ti < TI; ++ti) pa[ti] = split8<NS>(cur.a[ti][0], cur.a[ti][1]);
+        for (int ti = 0; ti < TI; ++ti) pa[ti] = split8_p(cur.a[ti][0], cur.a[ti][1], gs.g);
 #pragma unroll
-      for (int tj = 0; tj < TJ; ++tj) pb[tj] = split8<NS>(cur.b[tj][0], cur.b[tj][1]);
+        for (int tj = 0; tj < TJ; ++tj) pb[tj] = split8_q(cur.b[tj][0], cur.b[tj][1]);
 #pragma unroll
-      for (int tot = NS - 1; tot >= 0; --tot)
+        for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-        for (int sa = 0; sa <= tot; ++sa)
+          for (int tj = 0; tj < TJ; ++tj) mma_f16s(acc[ti][tj], pa[ti], pb[tj]);
+      } else {
+        constexpr int NP = NS == kF16S ? 1 : NS;
+        Parts<NP> pa[TI], pb[TJ];
 #pragma unroll
-          for (int ti = 0; ti < TI; ++ti)
+        for (int ti = 0; ti < TI; ++ti) pa[ti] = split8<NP>(cur.a[ti][0], cur.a[ti][1]);
 #pragma unroll
-            for (int tj = 0; tj < TJ; ++tj)
-              acc[ti][tj] = PINN_MFMA32_BF16(__builtin_bit_cast(bf16x8, pa[ti].p[sa]), __builtin_bit_cast(bf16x8, pb[tj].p[tot - sa]), acc[ti][tj]);
+        for (int tj = 0; tj < TJ; ++tj) pb[tj] = split8<NP>(cur.b[tj][0], cur.b[tj][1]);
+#pragma unroll
+        for (int tot = NP - 1; tot >= 0; --tot)
+#pragma unroll
+          for (int sa = 0; sa <= tot; ++sa)
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+              for (int tj = 0; tj < TJ; ++tj)
+                acc[ti][tj] = PINN_MFMA32_BF16(__builtin_bit_cast(bf16x8, pa[ti].p[sa]), __builtin_bit_cast(bf16x8, pb[tj].p[tot - sa]), acc[ti][tj]);
+      }
       if (row_sums) {
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
@@ -341,7 +437,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_d_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = i0 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        a.dW[so + (long long)row * a.IN + col] = acc[ti][tj][r];
+        a.dW[so + (long long)row * a.IN + col] = NS == kF16S ? acc[ti][tj][r] * gs.inv : acc[ti][tj][r];
       }
     }
   if (row_sums) {
@@ -358,9 +454,9 @@ static int launch_d(const WgradArgs& a, int ns, hipStream_t st) {
   const dim3 grid(a.n_slices, a.OUT / (TI * 32 * WI), a.IN / (TJ * 32 * WJ));
   const size_t lds = (size_t)WI * WJ * 2 * (TI + TJ) * 2048;
   auto k3 = wgrad_d_kernel<TI, TJ, WI, WJ, 3>;
-  auto k2 = wgrad_d_kernel<TI, TJ, WI, WJ, 2>;
   auto k1 = wgrad_d_kernel<TI, TJ, WI, WJ, 1>;
-  auto k = ns == 3 ? k3 : (ns == 2 ? k2 : k1);
+  auto k4 = wgrad_d_kernel<TI, TJ, WI, WJ, kF16S>;
+  auto k = ns == 3 ? k3 : (ns == kF16S ? k4 : k1);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -373,19 +469,21 @@ template <int TI, int TJ, int WI, int WJ>
 static void launch(const WgradArgs& a, int ns, hipStream_t st) {
   const dim3 grid(a.n_slices, a.OUT / (TI * 32 * WI), a.IN / (TJ * 32 * WJ));
   if (ns == 3) hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, 3>), grid, dim3(256), 0, st, a);
-  else if (ns == 2) hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, 2>), grid, dim3(256), 0, st, a);
+  else if (ns == kF16S) hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, kF16S>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, 1>), grid, dim3(256), 0, st, a);
 }
 
 }  // namespace x6
 
-// [OUT x IN] gradient with IN a multiple of 32 (every layer but the input one); ns = bf16 parts per operand (3: x6; 2: the
-// opt-in three-product form; 1: bf16-mixed, one product -- wide nets under PINN_PREC_BF16)
+// [OUT x IN] gradient with IN a multiple of 32 (every layer but the input one); ns = the operand split (4: two fp16 parts,
+// kF16S; 3: three bf16 parts, x6; 1: bf16-mixed, one product -- wide nets under PINN_PREC_BF16)
 int dispatch_wgrad_x6(const WgradArgs& a, int ns, void* stream) {
   using namespace x6;
   hipStream_t st = (hipStream_t)stream;
   const int to = a.OUT / 32, ti = a.IN / 32;
   if (a.Q == nullptr || a.IN % 32 || a.OUT % 32) return PINN_E_ARCH;
+  if (ns != 1 && ns != 3 && ns != x6::kF16S) return PINN_E_ARG;
+  if (ns == x6::kF16S && !a.amax) return PINN_E_ARG;
 #ifdef PINN_DEBUG_HOOKS
   static const bool direct = getenv("PINN_WGRAD_DIRECT") != nullptr;     // measurement builds only: the register-staged kernel everywhere
 #else

@@ -109,14 +109,13 @@ class DNN(torch.nn.Module):
 
     def set_precision(self, precision):
         """"fp32": exact fp32 matrix math (v_mfma_f32_*_f32; hidden <= 256 only).  "f32x6" (default): fp32-ACCURATE matrix
-        math on the 16-bit matrix cores from split operands, fp32 accumulation -- forward passes from two fp16 parts (three
-        products), gradients from three bf16 parts (six products); same parity tolerances as "fp32", 1.7x faster training
-        and 3x faster inference / MC-dropout.  "f32x6g3": as "f32x6" with the gradients from two parts too (gradient tensors
-        ~5e-6 of their largest element from float64; ~17 % faster; NOT inside the 3-step Adam trajectory tolerance of the
-        golden test).  "bf16": bf16 MFMA inputs, fp32 accumulate / activations / loss / master weights; rtol ~2e-2."""
-        codes = {"fp32": _lib.PREC_FP32, "bf16": _lib.PREC_BF16, "f32x6": _lib.PREC_F32X6, "f32x6g3": _lib.PREC_F32X6_G3}
+        math on the 16-bit matrix cores from split operands (two fp16 parts, three products, fp32 accumulation; gradients
+        under exact power-of-two scales) -- same parity tolerances as "fp32", 2-3x faster.  "f32x6g6": as "f32x6" with the
+        gradients from three bf16 parts / six products (24-bit operands, fp32's exponent range per element; ~20 % slower).
+        "bf16": bf16 MFMA inputs, fp32 accumulate / activations / loss / master weights; rtol ~2e-2."""
+        codes = {"fp32": _lib.PREC_FP32, "bf16": _lib.PREC_BF16, "f32x6": _lib.PREC_F32X6, "f32x6g6": _lib.PREC_F32X6_G6}
         if precision not in codes:
-            raise ValueError("precision must be 'fp32', 'f32x6', 'f32x6g3' or 'bf16'")
+            raise ValueError("precision must be 'fp32', 'f32x6', 'f32x6g6' or 'bf16'")
         self.precision = precision
         if precision == "fp32":
             self._net = _lib.Net(self.n_in, self.hidden, self.n_hidden, _lib.PREC_FP32, None)
