@@ -46,10 +46,12 @@ def test_host_only_entry_points(lib):
     assert lib.pinn_packed_bytes(ctypes.byref(_lib.Net(8, 256, 3, _lib.PREC_BF16))) == 688128
     assert lib.pinn_packed_bytes(ctypes.byref(_lib.Net(8, 256, 3))) == 0
     assert lib.pinn_train_workspace_bytes(ctypes.byref(_lib.Net(8, 256, 3, _lib.PREC_BF16, None)), 1000) == 0      # bf16 needs its scratch buffer
-    # wide nets (layer-by-layer kernels): sized by shape alone, x6 arithmetic only
+    # wide nets (layer-by-layer kernels): sized by shape alone; every precision but exact fp32 (which needs no scratch anywhere)
     assert lib.pinn_param_count(ctypes.byref(_lib.Net(8, 1024, 4))) == layout.param_offsets(8, 1024, 4)[1]
-    assert lib.pinn_packed_bytes(ctypes.byref(_lib.Net(8, 1024, 4, _lib.PREC_F32X6))) > 3 * 2 * 4 * 1024 * 1024
-    assert lib.pinn_packed_bytes(ctypes.byref(_lib.Net(8, 1024, 4, _lib.PREC_BF16))) == 0
+    wide_bytes = lib.pinn_packed_bytes(ctypes.byref(_lib.Net(8, 1024, 4, _lib.PREC_F32X6)))
+    assert wide_bytes > 5 * 2 * 4 * 1024 * 1024                 # five 16-bit copies of the matrices + the activation scratch
+    assert lib.pinn_packed_bytes(ctypes.byref(_lib.Net(8, 1024, 4, _lib.PREC_BF16))) == wide_bytes
+    assert lib.pinn_packed_bytes(ctypes.byref(_lib.Net(8, 1024, 4, _lib.PREC_FP32))) == 0
     assert lib.pinn_param_count(ctypes.byref(_lib.Net(8, 384, 2))) < 0
     for bad in (_lib.Net(8, 96, 3), _lib.Net(7, 256, 3), _lib.Net(8, 256, 0), _lib.Net(8, 384, 3), _lib.Net(8, 256, 9)):
         assert lib.pinn_param_count(ctypes.byref(bad)) == -2
