@@ -317,14 +317,14 @@ def leg_config5(dev):
     t_mc = _events(mc, 1, warm=0)
     peak = PEAK_BF16_MFMA_TFLOPS
     del work
-    # executed matrix FLOPs: forward layers 3 products per MAC (scheme X3), backward layers and weight gradients 6 (x6);
+    # executed matrix FLOPs: 3 products per MAC (scheme X3) in the forward layers, the backward layers and the weight gradients;
     # *_priced_at_6: round 1's convention (every product priced as six), kept so that the rounds compare
     alg = 2.0 * Mw
     tf = lambda flop, ms: flop / (ms * 1e-3) / 1e12
     return {"workload": "BASELINE configs[4] on one GPU: [8,1024x4,1] (M = %d MAC/row), %d rows; MC-dropout T = %d on %d rows" % (Mw, rows, T, mc_rows),
-            "products_per_mac": {"forward": 3, "backward": 6, "wgrad": 6},
+            "products_per_mac": {"forward": 3, "backward": 3, "wgrad": 3},
             "train": {"ms": t_all, "samples_per_s": rows / t_all * 1e3, "chain_ms": t_chain, "wgrad_ms": t_wg,
-                      "mfma_frac": tf((3 + 6 + 6) * alg * rows, t_all) / peak, "mfma_frac_priced_at_6": tf(18 * alg * rows, t_all) / peak},
+                      "mfma_frac": tf((3 + 3 + 3) * alg * rows, t_all) / peak, "mfma_frac_priced_at_6": tf(18 * alg * rows, t_all) / peak},
             "forward": {"ms": t_fwd, "algorithmic_TFLOPs": tf(alg * rows, t_fwd), "mfma_frac": tf(3 * alg * rows, t_fwd) / peak,
                         "mfma_frac_priced_at_6": tf(6 * alg * rows, t_fwd) / peak},
             "mc_dropout": {"seconds": t_mc * 1e-3, "fwd_passes_per_s": mc_rows * T / (t_mc * 1e-3),

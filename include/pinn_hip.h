@@ -158,11 +158,11 @@ int pinn_net_f_t(const float* d_x, const float* d_u, const float* d_x_halo, cons
 #define PINN_PREC_FP32 0  /* exact fp32 matrix math (v_mfma_f32_*_f32); parity with the reference at fp32 tolerance */
 #define PINN_PREC_BF16 1  /* bf16 MFMA inputs, fp32 accumulate / activations / loss / master weights (rtol ~2e-2)    */
 #define PINN_PREC_F32X6 2 /* fp32-ACCURATE matrix math on the 16-bit matrix cores from split operands, fp32 accumulation; same
-                             tolerances as PINN_PREC_FP32, 2-3x faster.  Fused nets (hidden <= 256): every product -- forward,
+                             tolerances as PINN_PREC_FP32, 2-3x faster.  Every product -- forward,
                              MC-dropout, backward chain, weight gradients -- from two fp16 parts per operand, three MFMAs
                              (gradients under exact power-of-two scales: per row in the backward chain, one per call in the
                              weight gradients); gradient tensors come out as close to a float64 autograd as torch's own fp32
-                             autograd does.  Wide nets: forward the same, gradients as PINN_PREC_F32X6_G6.  What the Python
+                             autograd does.  Wide nets (layer-by-layer kernels): the same schemes.  What the Python
                              surface uses by default.  (The name is round 1's, when every product took six MFMAs.) */
 #define PINN_PREC_F32X6_G6 3 /* as F32X6 with the gradients (backward chain, weight gradients) from three bf16 parts per operand,
                                 six MFMAs per product: 24-bit operands and fp32's full exponent range for every element

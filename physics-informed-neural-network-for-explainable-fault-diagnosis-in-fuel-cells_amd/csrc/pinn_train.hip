@@ -675,8 +675,8 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     if ((rc = dispatch_wgrad(g, st))) return rc;
     // every layer but the input one: split-bf16 products on the matrix cores for PINN_PREC_F32X6
     // operand split of the weight-gradient kernels: 0 = exact fp32 kernels; 3 = three bf16 parts, six products (x6); 4 = two fp16
-    // parts under the common scale the X3 backward chain measured (PINN_PREC_F32X6 on the fused nets); 1 = bf16-mixed (wide nets)
-    const int ns = net->precision == PINN_PREC_F32X6 ? (H <= 256 ? 4 : 3) : (net->precision == PINN_PREC_F32X6_G6 ? 3 : (net->precision == PINN_PREC_BF16 ? 1 : 0));
+    // parts under the common scale the X3 backward kernels measured (PINN_PREC_F32X6); 1 = bf16-mixed (wide nets)
+    const int ns = net->precision == PINN_PREC_F32X6 ? 4 : (net->precision == PINN_PREC_F32X6_G6 ? 3 : (net->precision == PINN_PREC_BF16 ? 1 : 0));
     auto wgrad = [&](const WgradArgs& wa) { return ns ? dispatch_wgrad_x6(wa, ns, stream) : dispatch_wgrad(wa, st); };
     for (int l = 1; l < nh; ++l) {
       g.P = a.dpre_h + l * hs; g.Q = a.stash_h + (l - 1) * hs; g.OUT = H; g.IN = H; g.dW = slabs + L.w(l); g.db = slabs + L.b(l);

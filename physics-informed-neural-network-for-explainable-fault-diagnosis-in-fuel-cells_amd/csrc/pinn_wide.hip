@@ -39,6 +39,9 @@ struct LayerArgs {
   const float* act;          // EPI_BACKWARD: post-dropout activation of the OUTPUT features, [T16][OUT][16]
   const float* init_w;       // EPI_BACKWARD, optional: accumulator starts at init_w[f] * init_s[row]
   const float* init_s;
+  const float* du;           // EPI_BACKWARD in scheme X3: d loss / d (u, z) per row -> the row's power-of-two normalisation
+  const float* dz;
+  unsigned* amax;            // EPI_BACKWARD in scheme X3: running max |d pre-activation| of the call (TrainBuffers::amax)
   long long n_rows, row_base;   // rows of this launch; global index of its first row (Philox) = drop.row_offset + chunk start
   int IN, OUT;
   unsigned mat_off;          // bf16-element offset of the [OUT][IN] matrix inside a copy
@@ -60,7 +63,9 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
   static_assert((S::kCopies << kNrb) % 8 == 0, "pieces must divide over the eight waves");
   constexpr int kRingBytes = 8 * 2 * 2048;
   constexpr int kSlabAt = (kRingBytes + 1023) & ~1023;
-  constexpr float kAct = S::kActScale, kAcc = S::kAccScale, kInvAcc = 1.0f / S::kAccScale;
+  constexpr float kAct = S::kActScale, kAcc = S::kAccScale, kInvAcc = 1.0f / S::kAccScale, kWs = S::kAccScale / S::kActScale;
+  constexpr bool kNormRows = EPI == EPI_BACKWARD && S::kActScale != 1.0f;      // X3 backward: gradients normalised per row
+  float amax = 0.0f;
   __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * Pipe::kSlab];
   Pipe pipe;
   pipe.lds = smem + kSlabAt;
@@ -82,6 +87,17 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
     const RowCtx c{lane, kq, a.row_base + lrow, lrow, a.n_rows, a.pass, a.drop.mode};
     const float* in_tile = a.in + t16 * a.IN * 16;
     auto fetch = [&](int g) { ring.fetch(in_tile + 32 * g * 16, g & 1); };
+    // scale of the B operand: activations x 8 (X3 forward); gradients x the row's normalisation 2^(4 - e), max(|du|, |dz|) =
+    // m 2^e (X3 backward, as backward_pass in pinn_x6_core.h); un-normalised again in the epilogue
+    float bsc = EPI == EPI_BACKWARD ? 1.0f : kAct, unr = 1.0f;
+    if constexpr (kNormRows) {
+      const float mxr = valid ? fmaxf(fabsf(a.du[lrow]), fabsf(a.dz[lrow])) : 0.0f;
+      int e = 0;
+      (void)frexpf(mxr, &e);
+      e = mxr > 0.0f ? (e < -120 ? -120 : e) : 4;
+      bsc = ldexpf(1.0f, 4 - e);
+      unr = ldexpf(1.0f, e - 4);
+    }
     // blocks 0 and 1 of this tile's input; block 0 is split at once (nothing to hide it under)
     fetch(0);
     fetch(1);
@@ -89,13 +105,13 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
     Frag cur, nxt;
     static_for<4>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
-      S::template split<r>(ring.read(0, 0, r) * kAct, ring.read(0, 1, r) * kAct, cur);
+      S::template split<r>(ring.read(0, 0, r) * bsc, ring.read(0, 1, r) * bsc, cur);
     });
 #pragma unroll 1
     for (int ob = 0; ob < nob; ++ob) {
       f32x4 acc[kNT];
       if (EPI == EPI_BACKWARD) {
-        const float s = (a.init_w && valid) ? a.init_s[lrow] : 0.0f;      // padded rows stay exactly zero down the chain
+        const float s = (a.init_w && valid) ? a.init_s[lrow] * (bsc * kWs) : 0.0f;      // padded rows stay exactly zero down the chain
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
           const f32x4 w = a.init_w ? *reinterpret_cast<const f32x4*>(a.init_w + ob * kOB + t * 16 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
           constexpr int ci = decltype(cc)::value, every = kNT / 4;
           if constexpr (ci % every == every - 1) {
             constexpr int r = ci / every;
-            S::template split<r>(ring.read(gb & 1, 0, r) * kAct, ring.read(gb & 1, 1, r) * kAct, nxt);
+            S::template split<r>(ring.read(gb & 1, 0, r) * bsc, ring.read(gb & 1, 1, r) * bsc, nxt);
           }
         };
         slab_mfma<S, kNT>(acc, cur, pipe.cur(), lane, vchunk, dma);
@@ -135,8 +151,9 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
       }
       // ---- epilogue of these output features (X3: the accumulators carry 512 x the pre-activation)
       if constexpr (kAcc != 1.0f) {
+        const float back = EPI == EPI_BACKWARD ? unr * (1.0f / kWs) : kInvAcc;
 #pragma unroll
-        for (int t = 0; t < kNT; ++t) acc[t] = acc[t] * kInvAcc;
+        for (int t = 0; t < kNT; ++t) acc[t] = acc[t] * back;
       }
       float* out_tile = a.out + (t16 * a.OUT + ob * kOB + 4 * kq) * 16 + (lane & 15);
       if (EPI == EPI_BACKWARD) {
@@ -152,6 +169,7 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
             const float av = hl[t][r] * inv_scale;
             const float gv = acc[t][r] * (scale * (1.0f - av * av));
             acc[t][r] = hl[t][r] != 0.0f ? gv : 0.0f;
+            if constexpr (kNormRows) amax = fmaxf(amax, fabsf(acc[t][r]));
           }
           store_block(out_tile, t, acc[t]);
         }
@@ -176,6 +194,11 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
         }
       }
     }
+  }
+  if constexpr (kNormRows) {          // the call's largest |d pre-activation|: the fp16 weight-gradient kernels' common scale
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    if (lane == 0) atomicMax(a.amax, __float_as_uint(amax));
   }
 }
 
@@ -299,8 +322,10 @@ struct LossArgs {
   long long n_rows, n_global;
   int H;
   long long wp_off, bp_off, wv2_off, bv2_off;
+  unsigned* amax;            // running max |d pre-activation| of the call (this kernel: d pre_v2), or nullptr
 };
 __global__ __launch_bounds__(256) void wide_loss_kernel(LossArgs a) {
+  float amax = 0.0f;
   __shared__ double red[4][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane >> 4;
   const long long n_t16 = (a.n_rows + 127) / 128 * 8;
@@ -353,9 +378,17 @@ __global__ __launch_bounds__(256) void wide_loss_kernel(LossArgs a) {
       load_block(vp, t, vv);
       const f32x4 w = *reinterpret_cast<const f32x4*>(a.params + a.wv2_off + t * 16 + 4 * kq);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) vv[r] = w[r] * dz * (1.0f - vv[r] * vv[r]);
+      for (int r = 0; r < 4; ++r) {
+        vv[r] = w[r] * dz * (1.0f - vv[r] * vv[r]);
+        amax = fmaxf(amax, fabsf(vv[r]));
+      }
       store_block(dp, t, vv);
     }
+  }
+  if (a.amax) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    if (lane == 0) atomicMax(a.amax, __float_as_uint(amax));
   }
   float terms[5] = {s_nll, s_abs, s_mse, s_du, s_dz};
 #pragma unroll
@@ -381,14 +414,14 @@ void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st
 }
 
 // scratch behind the packed weights (floats): two activation buffers, v1, v2, the MC sums
-// PINN_PREC_F32X6: forward layers in scheme X3 on the fp16 copies (behind the three bf16 ones), backward layers in x6;
+// PINN_PREC_F32X6: scheme X3 on the fp16 copies (behind the three bf16 ones), forward and backward (_G6: backward layers in x6);
 // PINN_PREC_BF16: one bf16 part per operand everywhere (the first bf16 copy)
 template <int EPI>
 static void launch_wide_layer(wide::LayerArgs la, int grid, hipStream_t st, int precision) {
   if (precision == PINN_PREC_BF16) {
     if (la.OUT % 256 == 0) hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::B1, EPI, 16>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
     else hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::B1, EPI, 8>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
-  } else if constexpr (EPI == wide::EPI_BACKWARD) {
+  } else if (EPI == wide::EPI_BACKWARD && precision == PINN_PREC_F32X6_G6) {
     if (la.OUT % 256 == 0) hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::X6, EPI, 16>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
     else hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::X6, EPI, 8>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
   } else {
@@ -500,8 +533,15 @@ int launch_train_chain_wide(const pinn_net_t* net, const float* d_params, const 
 
   const long long t4 = b.t16 / 4;
   const int grid_loss = (int)(t4 < 1024 ? (t4 < 1 ? 1 : t4) : 1024);
-  LossArgs lo{d_params, sh + (nh - 1) * hs, sv2, dv2, d_y, b.du, b.dz, b.loss_part, n_rows, n_global, H, L.wp(), L.bp(), L.wv2(), L.bv2()};
+  const bool x3_grads = net->precision == PINN_PREC_F32X6;          // gradients in scheme X3: the call's largest |d pre| is recorded
+  if (x3_grads) {
+    hipError_t em = hipMemsetAsync(b.amax, 0, sizeof(unsigned), st);
+    if (em != hipSuccess) return (int)em;
+  }
+  LossArgs lo{d_params, sh + (nh - 1) * hs, sv2, dv2, d_y, b.du, b.dz, b.loss_part, n_rows, n_global, H, L.wp(), L.bp(), L.wv2(), L.bv2(),
+              x3_grads ? b.amax : nullptr};
   hipLaunchKernelGGL(wide_loss_kernel, dim3(grid_loss), dim3(256), 0, st, lo);
+  la.du = b.du; la.dz = b.dz; la.amax = b.amax;
   *grid_out = grid_loss;
 
   // backward: Wv1^T, Wv0^T (+ w_p du), W_l^T for l = nh-1 .. 1
