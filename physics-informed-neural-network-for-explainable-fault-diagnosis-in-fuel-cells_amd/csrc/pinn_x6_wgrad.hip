@@ -389,6 +389,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_d_kernel(WgradArgs a) {
       fetch(clampt(t + 2), s0);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kFrags) : "memory");
       read(nxt, s0 ^ 1);
+      if (row_sums) {          // (before the split: the fp32 fragments are dead once their parts exist)
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg) bsum[ti] += (cur.a[ti][sg][0] + cur.a[ti][sg][1]) + (cur.a[ti][sg][2] + cur.a[ti][sg][3]);
+      }
       if constexpr (NS == kF16S) {
         PartsP pa[TI];
         PartsQ pb[TJ];
@@ -416,12 +422,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_d_kernel(WgradArgs a) {
 #pragma unroll
               for (int tj = 0; tj < TJ; ++tj)
                 acc[ti][tj] = PINN_MFMA32_BF16(__builtin_bit_cast(bf16x8, pa[ti].p[sa]), __builtin_bit_cast(bf16x8, pb[tj].p[tot - sa]), acc[ti][tj]);
-      }
-      if (row_sums) {
-#pragma unroll
-        for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-          for (int sg = 0; sg < 2; ++sg) bsum[ti] += (cur.a[ti][sg][0] + cur.a[ti][sg][1]) + (cur.a[ti][sg][2] + cur.a[ti][sg][3]);
       }
       cur = nxt;
     }
