@@ -49,6 +49,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_fwd_x3_kernel(Tra
   const int lane = threadIdx.x & 63, wave = pipe.wave, kq = lane >> 4;
   const float inv_n = (float)(1.0 / (double)a.n_global);
   float s_nll = 0.f, s_abs = 0.f, s_mse = 0.f, s_du = 0.f, s_dz = 0.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.b.amax = 0u;      // the backward kernel (next in the stream) takes its atomicMax from 0
 
   const long long n_tiles = (a.n_rows + 127) / 128 * (128 / kTileRowsX);      // whole 128-row stash tiles
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -187,7 +188,7 @@ int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const fl
   const bool bits = drop.mode == PINN_DROP_BITS;
   const bool fast_bwd = net->precision == PINN_PREC_F32X6;           // backward chain in scheme X3 (PINN_PREC_F32X6_G6: x6)
   const bool run_fwd = which & 1u, fwd_only = !(which & 2u);
-  if (fast_bwd && !fwd_only) {
+  if (fast_bwd && !fwd_only && !run_fwd) {          // backward alone (per-kernel timing): no forward kernel has reset the maximum
     hipError_t em = hipMemsetAsync(b.amax, 0, sizeof(unsigned), st);
     if (em != hipSuccess) return (int)em;
   }
