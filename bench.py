@@ -493,12 +493,12 @@ def main():
                          "frac": achieved / chain_peak, "traffic": None, "flop_per_row": CHAIN_FLOP_PER_ROW, "ms": ms_chain,
                          "products_per_mac": {"forward": pf, "backward": pb, "wgrad": pw},
                          "frac_if_priced_at_6_products": achieved / (peak1 / 6.0),
-                         "note": "achieved = algorithmic FLOP / time; peak = dense 16-bit MFMA peak / matrix instructions executed per "
-                                 "algorithmic product (products_per_mac), i.e. frac = utilisation of the matrix unit by the instructions "
-                                 "actually issued.  Round 1 issued six per product (peak 416.7, frac 0.354 = frac_if_priced_at_6_products "
-                                 "here); computing the same arithmetic with three halves frac's denominator-free meaning, not the work: "
-                                 "compare rounds on frac_if_priced_at_6_products or on value.  The chip is power-limited in these kernels "
-                                 "(DESIGN.md 3): a pure stream of these MFMAs sustains 58-66 % of the nominal peak",
+                         "note": "achieved = algorithmic FLOP / time.  peak = dense 16-bit MFMA peak / matrix instructions issued per "
+                                 "algorithmic product (products_per_mac), so frac is the utilisation of the matrix unit by the instructions "
+                                 "actually issued.  Round 1 issued six per product (peak 416.7; its frac 0.354 corresponds to "
+                                 "frac_if_priced_at_6_products here).  The same arithmetic from three instructions raises value and lowers "
+                                 "this frac: compare rounds on value or on frac_if_priced_at_6_products.  The chip is power-limited in these "
+                                 "kernels (DESIGN.md 3): a pure stream of these MFMAs sustains 58-66 % of the nominal peak",
                          "wgrad": {"ms": ms_wgrad, "achieved": wg, "frac": wg / (peak1 / pw)},
                          "reduce_ms": ms_reduce,
                          "step_mfma_frac": step_exec / (r["ms_per_step"] * 1e-3) / 1e12 / peak1,
