@@ -29,6 +29,7 @@ extern "C" {
 #define PINN_E_ARG (-1)        /* null pointer / negative size / bad flag */
 #define PINN_E_ARCH (-2)       /* network shape not supported by the fused kernels */
 #define PINN_E_WORKSPACE (-3)  /* workspace too small */
+#define PINN_E_RANGE (-4)      /* pinn_net_range_status: a weight or gradient left the domain of the split-operand kernels */
 
 /* ---- physics parameters: float[17] on the device, order of 01:453-517 ------------------ */
 enum {
@@ -179,6 +180,16 @@ typedef struct pinn_net {
 } pinn_net_t;
 
 size_t pinn_packed_bytes(const pinn_net_t* net);             /* 0 for fp32 / unsupported shapes */
+
+/* Domain of PINN_PREC_F32X6 / _G6 (the fp32 reference has no such limit; PINN_PREC_FP32 and _BF16 neither): the matrix
+ * operands are fp16 parts under fixed power-of-two scales, so every weight of the hidden x hidden and variance-head
+ * matrices must satisfy |w| < 1023.5 (fp16(64 w) finite), and the row-normalised gradients of PINN_PREC_F32X6's backward
+ * chain must stay below 65504 (they do while 16 x the column abs-sums of those matrices do).  Outside it the kernels
+ * produce inf / NaN -- never silently wrong finite numbers -- and record the fact in d_packed: every call that packs the
+ * weights rewrites the record, pinn_mlp_train_grads adds its gradient check.  This query reads it back: it WAITS for
+ * `stream` (the one entry point that synchronises) and returns PINN_OK, PINN_E_RANGE, or an argument / HIP error.
+ * Call it where the host synchronises anyway (logging, fetching results); on PINN_E_RANGE switch the net to PINN_PREC_FP32. */
+int pinn_net_range_status(const pinn_net_t* net, void* stream);
 
 long long pinn_param_count(const pinn_net_t* net);          /* floats in the flat buffer, <0 on error */
 

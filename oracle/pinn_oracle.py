@@ -52,44 +52,47 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return [c.astype(np.uint32) for c in (c0, c1, c2, c3)]
 
 
-DROPOUT_DRAW_BITS = 8
+DROPOUT_DRAW_BITS = 16
 
 
-def dropout_threshold8(p):
-    """8-bit drop threshold: element kept iff its 8-bit draw >= thr. P(keep) = 1 - thr/256
-    (|P(keep) - (1 - p)| <= 2^-9; SURVEY.md section 7: "8-16 random bits per draw")."""
-    return int(min(256, max(0, math.floor(float(p) * 256.0 + 0.5))))
+def dropout_threshold16(p):
+    """16-bit drop threshold: element kept iff its 16-bit draw >= thr.  P(keep) = 1 - thr/65536, so under the
+    reference's 1 / (1 - p) scale (01:405-406) the expected mask * scale is 1 to 2^-17 / (1 - p) (p = 0.2: 3.8e-6).
+    A positive p never rounds to "no dropout" (thr >= 1).  (Round 2 used 8-bit draws: +0.1 % / +0.26 % expected
+    gain per dropout layer at p = 0.2 / 0.4 -- VERDICT r2.)"""
+    p = float(p)
+    thr = int(min(65536, max(0, math.floor(p * 65536.0 + 0.5))))
+    return max(thr, 1) if p > 0.0 else thr
 
 
 def philox_keep_mask(seed, stream, row0, n_rows, layer_id, width, p):
     """Keep-mask [n_rows, width] (bool) of one dropout layer -- the on-chip mask specification.
 
-    One Philox call yields sixteen 8-bit draws.  For feature f of dropout layer `layer_id`
+    One Philox call yields eight 16-bit draws.  For feature f of dropout layer `layer_id`
     (0-based over the net's Dropout modules) and GLOBAL row index g = row0 + r:
         counter = (g & 0xffffffff, g >> 32, layer_id << 16 | call, stream),  key = (seed lo, hi)
-        call = (f >> 6) << 2 | ((f >> 2) & 3)
-        idx  = 8 * ((f >> 5) & 1) + 4 * ((f >> 4) & 1) + (f & 3);  word = idx >> 2,  byte = idx & 3  (0 = low byte)
-    (the sixteen features {64P + 32s + 16b + 4q + r : s, b in 0..1, r in 0..3} that one MFMA lane
-    holds in a pair of 32-feature K-groups share one call), so a mask depends only on (seed, stream,
-    global row, layer, feature): it is invariant under any row -> GPU / workgroup / lane assignment
-    (SURVEY.md 8(e), 9.4).  `stream` is the optimizer step (training) or the pass index (MC-dropout).
+        call = (f >> 5) << 2 | ((f >> 2) & 3)
+        idx  = 4 * ((f >> 4) & 1) + (f & 3);  word = idx >> 1,  half = idx & 1  (0 = low 16 bits)
+    (the eight features {32P + 16b + 4q + r : b in 0..1, r in 0..3} that one MFMA lane holds in a
+    32-feature K-group share one call), so a mask depends only on (seed, stream, global row, layer,
+    feature): it is invariant under any row -> GPU / workgroup / lane assignment.
+    `stream` is the optimizer step (training) or the pass index (MC-dropout).
     """
-    thr = dropout_threshold8(p)
+    thr = dropout_threshold16(p)
     g = (np.arange(n_rows, dtype=np.uint64) + np.uint64(row0))[:, None]
     f = np.arange(width, dtype=np.uint64)[None, :]
-    call = ((f >> np.uint64(6)) << np.uint64(2)) | ((f >> np.uint64(2)) & np.uint64(3))
-    idx = (np.uint64(8) * ((f >> np.uint64(5)) & np.uint64(1)) + np.uint64(4) * ((f >> np.uint64(4)) & np.uint64(1))
-           + (f & np.uint64(3))).astype(np.int64)
-    word = idx >> 2
-    byte = idx & 3
+    call = ((f >> np.uint64(5)) << np.uint64(2)) | ((f >> np.uint64(2)) & np.uint64(3))
+    idx = (np.uint64(4) * ((f >> np.uint64(4)) & np.uint64(1)) + (f & np.uint64(3))).astype(np.int64)
+    word = idx >> 1
+    half = idx & 1
     c2 = (np.uint64(layer_id) << np.uint64(16)) | call
     out = philox4x32_10(g & _MASK32, g >> np.uint64(32), c2, np.uint64(int(stream) & 0xFFFFFFFF),
                         int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
     words = np.stack(out, axis=0)                                    # [4, n_rows, width]
     word_b = np.broadcast_to(word, (n_rows, width))
     sel = np.take_along_axis(words, word_b[None, :, :], axis=0)[0]
-    draw = (sel >> (np.uint32(8) * byte.astype(np.uint32))) & np.uint32(0xFF)
-    return draw >= np.uint32(thr) if thr < 256 else np.zeros((n_rows, width), dtype=bool)
+    draw = (sel >> (np.uint32(16) * half.astype(np.uint32))) & np.uint32(0xFFFF)
+    return draw >= np.uint32(thr) if thr < 65536 else np.zeros((n_rows, width), dtype=bool)
 
 
 def philox_masks_for_net(seed, stream, row0, n_rows, hidden, n_hidden, p_list):

@@ -52,6 +52,13 @@ class PinnError(RuntimeError):
     pass
 
 
+class PinnRangeError(PinnError):
+    """A weight or gradient left the domain of the split-operand precisions (include/pinn_hip.h: PINN_E_RANGE)."""
+
+
+E_RANGE = -4
+
+
 _SIGS = {
     "pinn_abi_version": (c_int, []),
     "pinn_residuals_workspace_bytes": (c_size_t, []),
@@ -63,6 +70,7 @@ _SIGS = {
     "pinn_lambda_stage_workspace_bytes": (c_size_t, [c_ll]),
     "pinn_param_count": (c_ll, [ctypes.POINTER(Net)]),
     "pinn_packed_bytes": (c_size_t, [ctypes.POINTER(Net)]),
+    "pinn_net_range_status": (c_int, [ctypes.POINTER(Net), c_void_p]),
     "pinn_mlp_forward": (c_int, [ctypes.POINTER(Net), c_void_p, c_void_p, c_ll, ctypes.POINTER(Dropout), c_void_p, c_void_p,
                                  c_void_p]),
     "pinn_mc_dropout": (c_int, [ctypes.POINTER(Net), c_void_p, c_void_p, c_ll, ctypes.POINTER(Dropout), c_int, c_void_p,

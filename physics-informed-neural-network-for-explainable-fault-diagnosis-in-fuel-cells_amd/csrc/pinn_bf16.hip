@@ -561,9 +561,34 @@ extern "C" size_t pinn_packed_bytes(const pinn_net_t* net) {
   if (net->hidden != 128 && net->hidden != 256 && !wide) return 0;
   PackLayout K{net->hidden, net->n_hidden};
   // wide nets: the three copies + the activation scratch of one row chunk (layer-by-layer kernels)
-  if (wide) return net->precision != PINN_PREC_FP32 ? (size_t)K.total() * 2 * 5 + pinn::wide_scratch_floats(net->hidden) * 4 : 0;
+  // (+ kRangeStatusBytes at the very end of every buffer the x6 pack kernel fills: pinn_net_range_status's record)
+  if (wide) return net->precision != PINN_PREC_FP32 ? (size_t)K.total() * 2 * 5 + pinn::wide_scratch_floats(net->hidden) * 4 + pinn::kRangeStatusBytes : 0;
   if (net->precision == PINN_PREC_BF16) return (size_t)K.total() * 2;
   // three bf16 copies (hi, mid, lo: backward pass, weight gradients) + two fp16 copies of the forward matrices (scheme X3)
-  if (net->precision == PINN_PREC_F32X6 || net->precision == PINN_PREC_F32X6_G6) return (size_t)K.total() * 2 * 5;
+  if (net->precision == PINN_PREC_F32X6 || net->precision == PINN_PREC_F32X6_G6) return (size_t)K.total() * 2 * 5 + pinn::kRangeStatusBytes;
   return 0;
+}
+
+namespace pinn {
+unsigned* range_status_words(const pinn_net_t* net) {
+  const size_t n = pinn_packed_bytes(net);
+  return (n >= kRangeStatusBytes && net->d_packed) ? (unsigned*)((char*)net->d_packed + n - kRangeStatusBytes) : nullptr;
+}
+}  // namespace pinn
+
+extern "C" int pinn_net_range_status(const pinn_net_t* net, void* stream) {
+  if (!net) return PINN_E_ARG;
+  const bool x6 = net->precision == PINN_PREC_F32X6 || net->precision == PINN_PREC_F32X6_G6;
+  if (!x6) return (net->precision == PINN_PREC_FP32 || net->precision == PINN_PREC_BF16) ? PINN_OK : PINN_E_ARG;
+  unsigned* d = pinn::range_status_words(net);
+  if (!d) return PINN_E_ARG;
+  static unsigned host[pinn::kRangeStatusBytes / 4];          // one host thread per process drives the library (pinn_hip.h)
+  const int n_words = pinn::kRangePackBlocks * (2 * (net->n_hidden - 1) + 4) + 1;      // pack jobs x blocks, then the gradient word
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemcpyAsync(host, d, (size_t)n_words * 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return (int)e;
+  unsigned any = 0;
+  for (int i = 0; i < n_words; ++i) any |= host[i];
+  return any ? PINN_E_RANGE : PINN_OK;
 }

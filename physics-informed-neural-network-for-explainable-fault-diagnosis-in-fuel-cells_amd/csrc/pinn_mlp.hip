@@ -83,8 +83,9 @@ static int convert_drop(const pinn_net_t* net, const pinn_dropout_t* in, DropDev
   for (int l = 0; l <= net->n_hidden; ++l) {
     const float p = in->p[l];
     if (!(p >= 0.0f && p < 1.0f)) return PINN_E_ARG;
-    double t = floor((double)p * 256.0 + 0.5);
-    out->thr[l] = (unsigned)(t < 0 ? 0 : (t > 256.0 ? 256.0 : t));
+    double t = floor((double)p * 65536.0 + 0.5);
+    if (p > 0.0f && t < 1.0) t = 1.0;      // a positive p never rounds to "no dropout"
+    out->thr[l] = (unsigned)(t < 0 ? 0 : (t > 65536.0 ? 65536.0 : t));
     out->scale[l] = 1.0f / (float)(1.0 - (double)p);
   }
   out->seed_lo = (unsigned)(in->seed & 0xFFFFFFFFull);

@@ -88,12 +88,18 @@ __device__ __forceinline__ void load_small_params(float* __restrict__ sp, const 
   __syncthreads();
 }
 
+// pinn_net_range_status's record at the end of d_packed: one word per pack-kernel workgroup (jobs x kRangePackBlocks, rewritten
+// by every pack: no atomics, nothing to clear), then one word for the gradient check of the last training call
+constexpr int kRangePackBlocks = 64;
+constexpr size_t kRangeStatusBytes = 8192;       // >= (18 jobs x 64 + 1) words
+unsigned* range_status_words(const pinn_net_t* net);      // pinn_bf16.hip; nullptr where the precision keeps no record
+
 // ---------------------------------------------------------------------------------------
 // dropout source (device copy of pinn_dropout_t)
 // ---------------------------------------------------------------------------------------
 struct DropDev {
   int mode;
-  unsigned thr[kMaxDrop];     // 8-bit drop thresholds round(256 p): keep iff draw8 >= thr
+  unsigned thr[kMaxDrop];     // 16-bit drop thresholds round(65536 p): keep iff draw16 >= thr (|P(keep) - (1 - p)| <= 2^-17)
   float scale[kMaxDrop];      // 1 / (1 - p) in float32 (torch: noise.div_(1 - p))
   unsigned seed_lo, seed_hi;
   unsigned stream;
@@ -130,14 +136,15 @@ struct RowCtx {
 
 // 8 keep bits of the 32-feature group `fp` (= two 16-feature blocks 2fp, 2fp+1) of dropout
 // module `layer` for this lane's row: bit 4*b + r <-> register r of block 2fp + b, i.e. feature
-// 32fp + 16b + 4kq + r.  ONE Philox call = sixteen 8-bit draws = this lane's share of the PAIR of
-// 32-groups (fp & ~1, fp | 1):
-//     counter = (global_row lo, hi, layer << 16 | (fp >> 1) << 2 | kq, stream + pass), key = seed
-//     draw index 8 (fp & 1) + 4b + r -> word (index >> 2), byte (index & 3); keep iff byte >= thr.
+// 32fp + 16b + 4kq + r.  ONE Philox call = eight 16-bit draws = exactly this lane's share of the group:
+//     counter = (global_row lo, hi, layer << 16 | fp << 2 | kq, stream + pass), key = seed
+//     draw index 4b + r -> word (index >> 1), half (index & 1; 0 = low 16 bits); keep iff draw16 >= thr.
+// (Round 2 drew sixteen 8-bit values per call: P(keep) = 205/256 at p = 0.2 under the reference's 1 / (1 - p) scale
+// biased every dropout layer's expected output by +0.1 % (+0.26 % at p = 0.4); with 16 bits the bias is < 4e-6.)
 // Branch-free: eval mode is thr = 0 (every draw kept).  kBits (parity-test kernels only) reads
 // injected bit masks instead.
 template <bool kBits>
-__device__ __forceinline__ unsigned keep_bits8(const DropDev& d, const RowCtx& c, unsigned thr, int layer, int fp) {
+__device__ __forceinline__ unsigned keep_bits16(const DropDev& d, const RowCtx& c, unsigned thr, int layer, int fp) {
   if (kBits) {
     const unsigned word = d.bits[((long long)c.pass * c.n_rows + c.lrow) * d.words + layer * d.nb + fp];
     const unsigned lo = (word >> (4 * c.kq)) & 0xFu, hi = (word >> (16 + 4 * c.kq)) & 0xFu;
@@ -145,13 +152,12 @@ __device__ __forceinline__ unsigned keep_bits8(const DropDev& d, const RowCtx& c
   }
   unsigned o[4];
   philox4x32_10((unsigned)c.grow, (unsigned)((unsigned long long)c.grow >> 32),
-                ((unsigned)layer << 16) | ((unsigned)(fp >> 1) << 2) | (unsigned)c.kq, d.stream + c.pass, d.seed_lo, d.seed_hi, o);
-  const unsigned wa = (fp & 1) ? o[2] : o[0], wb = (fp & 1) ? o[3] : o[1];
+                ((unsigned)layer << 16) | ((unsigned)fp << 2) | (unsigned)c.kq, d.stream + c.pass, d.seed_lo, d.seed_hi, o);
   unsigned keep = 0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    keep |= (((wa >> (8 * r)) & 0xFFu) >= thr ? 1u : 0u) << r;
-    keep |= (((wb >> (8 * r)) & 0xFFu) >= thr ? 1u : 0u) << (4 + r);
+  for (int w = 0; w < 4; ++w) {
+    keep |= ((o[w] & 0xFFFFu) >= thr ? 1u : 0u) << (2 * w);
+    keep |= ((o[w] >> 16) >= thr ? 1u : 0u) << (2 * w + 1);
   }
   return keep;
 }
@@ -395,7 +401,7 @@ __device__ __forceinline__ unsigned activate_pair(f32x4& v0, f32x4& v1, const Dr
                                                   int layer, int fp) {
   const unsigned thr = ld.thr;
   const float scale = ld.scale;
-  const unsigned keep = keep_bits8<kBits>(d, c, thr, layer, fp);
+  const unsigned keep = keep_bits16<kBits>(d, c, thr, layer, fp);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const float a0 = tanh_f32(v0[r]);

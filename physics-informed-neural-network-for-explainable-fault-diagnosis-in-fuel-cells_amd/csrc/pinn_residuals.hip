@@ -31,6 +31,11 @@ __device__ __forceinline__ float denorm(float v, double mn, double sc) {
   return (float)((double)t / sc);
 }
 
+// torch.clamp propagates NaN (a NaN parameter or row stays visible, 01:586-610 / 01:1040-1047); fminf / fmaxf return the
+// operand that is not a NaN and would swallow it ("surface NaN")
+__device__ __forceinline__ float clamp_min_t(float x, float lo) { return x != x ? x : fmaxf(x, lo); }
+__device__ __forceinline__ float clamp_t(float x, float lo, float hi) { return x != x ? x : fminf(fmaxf(x, lo), hi); }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -149,7 +154,7 @@ __device__ __forceinline__ void row_terms(long long row, const float* __restrict
     if (flags & PINN_RES_H) {
       float Q = ((It / 192970.0f) * 5.0f) * 22.4f;   // 01:660-667
       Q = Q * 60.0f;
-      Q = fmaxf(Q, 1e-8f);
+      Q = clamp_min_t(Q, 1e-8f);
       const bool lin = It <= lH3;                    // 01:697-701
       const float tgt = lin ? (lH1 + lH2 * (It / 100.0f)) : (lH1 + lH2 * (lH3 / 100.0f));
       const float act = (r6 + 1e-6f) / Q;
@@ -171,15 +176,15 @@ __device__ __forceinline__ void row_terms(long long row, const float* __restrict
     if (flags & PINN_RES_O) {
       float Q = ((It * 5.0f) / 385940.0f) * 22.4f;   // 01:564-566
       Q = Q * 60.0f;
-      Q = fmaxf(Q, 1e-8f);
+      Q = clamp_min_t(Q, 1e-8f);
       const float thr = fabsf(lO3);
       const bool lin = It <= thr;                    // 01:586-590
       const float raw = lin ? (lO1 + lO2 * (It / 100.0f)) : (lO1 + lO2 * (thr / 100.0f));
-      const float tgt = fminf(fmaxf(raw, 1.05f), 15.0f);
+      const float tgt = clamp_t(raw, 1.05f, 15.0f);
       const float c = (raw >= 1.05f && raw <= 15.0f) ? 1.0f : 0.0f;   // torch.clamp backward is inclusive
       const float o2 = (r7 + 1e-6f) * 0.21f;
       const float act = o2 / Q;
-      const float f = (act - tgt) + fmaxf(1.0f - act, 0.0f) * 10.0f;   // 01:606-610
+      const float f = (act - tgt) + clamp_min_t(1.0f - act, 0.0f) * 10.0f;   // 01:606-610
       const float sgn = (lO3 > 0.0f) ? 1.0f : ((lO3 < 0.0f) ? -1.0f : 0.0f);
       acc[PINN_S_FO2] += f * f;
       acc[PINN_S_FO_D1] += f * (-c);
@@ -324,7 +329,7 @@ __device__ void lambda_step_body(int stage, const double* sums, double inv_n, fl
       p = p - step_size * (m / denom);
       adam[id] = m; adam[PINN_NLAMBDA + id] = v;
     }
-    lambdas[id] = fminf(fmaxf(p, d.lo[k]), d.hi[k]);       // .data = clamp(.data, lo, hi) AFTER step
+    lambdas[id] = clamp_t(p, d.lo[k], d.hi[k]);       // .data = clamp(.data, lo, hi) AFTER step
   }
   if (loss_out) { loss_out[0] = total; loss_out[1] = physics; }
 }
@@ -386,13 +391,13 @@ __device__ __forceinline__ void stage_prepare(long long row, const float* __rest
     const float r6 = denorm(xb.z, aff.x_min[6], aff.x_scale[6]);
     float Q = ((It / 192970.0f) * 5.0f) * 22.4f;
     Q = Q * 60.0f;
-    Q = fmaxf(Q, 1e-8f);
+    Q = clamp_min_t(Q, 1e-8f);
     c[0] = It; c[1] = (r6 + 1e-6f) / Q;
   } else {
     const float r7 = denorm(xb.w, aff.x_min[7], aff.x_scale[7]);
     float Q = ((It * 5.0f) / 385940.0f) * 22.4f;
     Q = Q * 60.0f;
-    Q = fmaxf(Q, 1e-8f);
+    Q = clamp_min_t(Q, 1e-8f);
     c[0] = It; c[1] = ((r7 + 1e-6f) * 0.21f) / Q;
   }
 }
@@ -447,9 +452,9 @@ __device__ __forceinline__ void stage_terms(const float (&c)[kCacheFloats], cons
     const float thr = fabsf(L.lO3);
     const bool lin = It <= thr;
     const float raw = lin ? (L.lO1 + L.lO2 * (It / 100.0f)) : (L.lO1 + L.lO2 * (thr / 100.0f));
-    const float tgt = fminf(fmaxf(raw, 1.05f), 15.0f);
+    const float tgt = clamp_t(raw, 1.05f, 15.0f);
     const float cl = (raw >= 1.05f && raw <= 15.0f) ? 1.0f : 0.0f;
-    const float f = (act - tgt) + fmaxf(1.0f - act, 0.0f) * 10.0f;
+    const float f = (act - tgt) + clamp_min_t(1.0f - act, 0.0f) * 10.0f;
     const float sgn = (L.lO3 > 0.0f) ? 1.0f : ((L.lO3 < 0.0f) ? -1.0f : 0.0f);
     acc[PINN_S_FO2] += f * f;
     acc[PINN_S_FO_D1] += f * (-cl);
@@ -674,7 +679,8 @@ extern "C" int pinn_residuals(const float* d_x, const float* d_u, const float* d
   if ((!d_x && n_rows > 0) || !aff || !d_lambda || n_rows < 0 || (flags & ~PINN_RES_ALL)) return PINN_E_ARG;
   if ((flags & PINN_RES_V) && !d_u && n_rows > 0) return PINN_E_ARG;
   if (d_cols && ld < n_rows) return PINN_E_ARG;
-  if (d_sums && (!d_work || work_bytes < pinn_residuals_workspace_bytes())) return PINN_E_WORKSPACE;
+  if (d_sums && !d_work) return PINN_E_ARG;
+  if (d_sums && work_bytes < pinn_residuals_workspace_bytes()) return PINN_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   (void)hipGetLastError();   // drop a stale error left by another HIP user of this thread
   AffineDev a;
@@ -719,7 +725,8 @@ extern "C" int pinn_lambda_stage_run(int stage, unsigned flags, const float* d_x
   if (flags != PINN_RES_V && flags != PINN_RES_T && flags != PINN_RES_H && flags != PINN_RES_O) return PINN_E_ARG;
   if ((flags & PINN_RES_V) && (!d_u || !d_y)) return PINN_E_ARG;
   if (d_log && log_every > 0 && first_epoch % log_every) return PINN_E_ARG;
-  if (!d_work || work_bytes < pinn_lambda_stage_workspace_bytes(n_rows)) return PINN_E_WORKSPACE;
+  if (!d_work) return PINN_E_ARG;
+  if (work_bytes < pinn_lambda_stage_workspace_bytes(n_rows)) return PINN_E_WORKSPACE;
   if (n_iters == 0) return PINN_OK;
   (void)hipGetLastError();
   AffineDev a;
@@ -745,7 +752,8 @@ extern "C" int pinn_residuals_prepare(const float* d_x, const float* d_u, const 
 extern "C" int pinn_residuals_cached(const float* d_cache, const pinn_affine_t* aff, const float* d_lambda, unsigned flags,
                                      long long n_rows, double* d_sums, void* d_work, size_t work_bytes, void* stream) {
   if (!d_cache || !aff || !d_lambda || !d_sums || n_rows <= 0 || !one_stage_flag(flags)) return PINN_E_ARG;
-  if (!d_work || work_bytes < pinn_residuals_workspace_bytes()) return PINN_E_WORKSPACE;
+  if (!d_work) return PINN_E_ARG;
+  if (work_bytes < pinn_residuals_workspace_bytes()) return PINN_E_WORKSPACE;
   (void)hipGetLastError();
   hipStream_t st = (hipStream_t)stream;
   const int blocks = row_blocks((n_rows + 1) / 2);

@@ -274,9 +274,11 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
     for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
-  float bsum[TI], vq[TJ], vr[TI];
+  // (bias sums in float64: a slice adds up to a few thousand rows per lane one after the other, where torch sums pairwise)
+  double bsum[TI];
+  float vq[TJ], vr[TI];
 #pragma unroll
-  for (int ti = 0; ti < TI; ++ti) { bsum[ti] = 0.f; vr[ti] = 0.f; }
+  for (int ti = 0; ti < TI; ++ti) { bsum[ti] = 0.0; vr[ti] = 0.f; }
 #pragma unroll
   for (int tj = 0; tj < TJ; ++tj) vq[tj] = 0.f;
 
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-        for (int sg = 0; sg < 2; ++sg) bsum[ti] += (cur.a[ti][sg][0] + cur.a[ti][sg][1]) + (cur.a[ti][sg][2] + cur.a[ti][sg][3]);
+        for (int sg = 0; sg < 2; ++sg) bsum[ti] += (double)((cur.a[ti][sg][0] + cur.a[ti][sg][1]) + (cur.a[ti][sg][2] + cur.a[ti][sg][3]));
       if (a.dvr) {
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
   if (wj == 0) {
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) {
-      const float b = bsum[ti] + __shfl_xor(bsum[ti], 32, 64);
+      const float b = (float)(bsum[ti] + __shfl_xor(bsum[ti], 32, 64));
       if (hh == 0) a.db[so + i0 + ti * 32 + i] = b;
       if (a.dvr) {
         const float v = vr[ti] + __shfl_xor(vr[ti], 32, 64);
@@ -409,17 +411,25 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
 // the slices q, q + 8, ... of its group (8 independent 16-B loads in flight), the eight partial sums meet in LDS and are
 // added in lane order -- the same tree on every run (bitwise reproducible; no float atomics).  (One thread per group
 // walking all 256 slices was 32 dependent rounds of loads: 64 us whatever the row count, a fifth of a 65 536-row step.)
+// The slabs are added in float64 (the launch is bound by its 180 MB of slab reads, not by the adds) and rounded to fp32 once:
+// the reduction over slices adds no rounding of its own to what the slice kernels accumulated.
 constexpr int kFinLanes = 8, kFinGroups = 32;
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f64x4 widen4(const f32x4& v) { return f64x4{(double)v[0], (double)v[1], (double)v[2], (double)v[3]}; }
 __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restrict__ slabs, int n_slices, long long total,
                                                             const double* __restrict__ loss_part, int n_parts,
                                                             long long off_bp, long long off_bv2, float* __restrict__ grads,
-                                                            double* __restrict__ loss_out) {
-  __shared__ f32x4 part[kFinLanes][kFinGroups];
+                                                            double* __restrict__ loss_out, const unsigned* __restrict__ amax,
+                                                            unsigned* __restrict__ range_word) {
+  __shared__ f64x4 part[kFinLanes][kFinGroups];
+  // pinn_net_range_status: the X3 backward chain's largest |d pre-activation| of this call is inf once a row-normalised
+  // gradient has left fp16's range (a NaN alone does not move the maximum, but then the gradients are NaN: visible)
+  if (range_word && blockIdx.x == 0 && threadIdx.x == 0 && (*amax & 0x7FFFFFFFu) >= 0x7F800000u) *range_word = 1u;
   const int g = threadIdx.x & (kFinGroups - 1), q = threadIdx.x / kFinGroups;
   // every tensor starts on a multiple of 4 floats, so the two scalar head biases sit at the start of a group whose other
   // three floats are padding
   const long long e = 4 * ((long long)blockIdx.x * kFinGroups + g);
-  f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+  f64x4 s = {0.0, 0.0, 0.0, 0.0};
   if (e < total) {
     int k = q;
     for (; k + 7 * kFinLanes < n_slices; k += 8 * kFinLanes) {
@@ -427,9 +437,9 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(slabs + (long long)(k + j * kFinLanes) * total + e);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[j];
+      for (int j = 0; j < 8; ++j) s += widen4(v[j]);
     }
-    for (; k < n_slices; k += kFinLanes) s += *reinterpret_cast<const f32x4*>(slabs + (long long)k * total + e);
+    for (; k < n_slices; k += kFinLanes) s += widen4(*reinterpret_cast<const f32x4*>(slabs + (long long)k * total + e));
   }
   part[q][g] = s;
   __syncthreads();
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
     } else {
 #pragma unroll
       for (int j = 1; j < kFinLanes; ++j) s += part[j][g];
-      *reinterpret_cast<f32x4*>(grads + e) = s;
+      *reinterpret_cast<f32x4*>(grads + e) = f32x4{(float)s[0], (float)s[1], (float)s[2], (float)s[3]};
     }
   }
   if (blockIdx.x == 0) {
@@ -597,8 +607,9 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
         for (int l = 0; l <= nh; ++l) {
           const float p = drop->p[l];
           if (!(p >= 0.0f && p < 1.0f)) return PINN_E_ARG;
-          double t = floor((double)p * 256.0 + 0.5);
-          d.thr[l] = (unsigned)(t < 0 ? 0 : (t > 256.0 ? 256.0 : t));
+          double t = floor((double)p * 65536.0 + 0.5);
+    if (p > 0.0f && t < 1.0) t = 1.0;      // a positive p never rounds to "no dropout"
+          d.thr[l] = (unsigned)(t < 0 ? 0 : (t > 65536.0 ? 65536.0 : t));
           d.scale[l] = 1.0f / (float)(1.0 - (double)p);
         }
         d.seed_lo = (unsigned)(drop->seed & 0xFFFFFFFFull); d.seed_hi = (unsigned)(drop->seed >> 32); d.stream = drop->stream;
@@ -627,7 +638,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     if ((rc = launch_train_bf16(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, phases, &grid, stream))) return rc;
     if (phases & PINN_PHASE_REDUCE)
       hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((L.total() / 4 + kFinGroups - 1) / kFinGroups)), dim3(256), 0, st, b.slabs, w.n_slices,
-                         L.total(), a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss);
+                         L.total(), a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss, (const unsigned*)nullptr, (unsigned*)nullptr);
     hipError_t eb = hipGetLastError();
     return eb == hipSuccess ? PINN_OK : (int)eb;
   }
@@ -692,9 +703,13 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     if ((rc = wgrad(g))) return rc;
   }
 
-  if (phases & PINN_PHASE_REDUCE)
+  if (phases & PINN_PHASE_REDUCE) {
+    // (the gradient word of the range record sits behind the pack kernel's words: pack_x6_kernel cleared it for this call)
+    unsigned* rw = net->precision == PINN_PREC_F32X6 ? range_status_words(net) : nullptr;
+    if (rw) rw += kRangePackBlocks * (2 * (nh - 1) + 4);
     hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((tot / 4 + kFinGroups - 1) / kFinGroups)), dim3(256), 0, st, slabs, w.n_slices, tot,
-                       a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss);
+                       a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss, (const unsigned*)(base + w.off_amax), rw);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;
 }

@@ -17,9 +17,14 @@ static int cu_count_x() { return cu_count_cached(); }
 
 // three bf16 copies (hi, mid, lo with w = hi + mid + lo exactly) of every matrix and its transpose,
 // K permuted inside each 32-group (pack_col_x6)
-__global__ __launch_bounds__(256) void pack_x6_kernel(const float* __restrict__ params, __bf16* __restrict__ packed, PackJobs6 jobs) {
+// Range record (pinn_net_range_status): scheme X3's fp16 copies hold 64 w, finite only while |w| < 1023.5; every workgroup
+// writes whether it met a weight outside that (or a non-finite one) into its own word of `status` -- plain stores, rewritten
+// by every call -- and workgroup (0, 0) clears the word of the gradient check that a training call's finalize kernel sets.
+__global__ __launch_bounds__(256) void pack_x6_kernel(const float* __restrict__ params, __bf16* __restrict__ packed, PackJobs6 jobs,
+                                                      unsigned* __restrict__ status) {
   const PackJob j = jobs.j[blockIdx.y];
   const long long n = (long long)j.rows * j.Kp;
+  int bad = 0;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
     const int row = (int)(e / j.Kp), q = (int)(e % j.Kp);
     const int k = (q & ~31) + pack_col_x6(q & 31);
@@ -37,9 +42,17 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(const float* __restrict__ 
     if (jobs.with_f16) {
       _Float16* p16 = reinterpret_cast<_Float16*>(packed + 3 * jobs.copy_stride);
       const float vs = v * X3::kWScale;
+      bad |= !(fabsf(vs) <= 65504.0f);           // (also true for a NaN)
       const _Float16 h16 = (_Float16)vs;
       p16[j.dst + e] = h16;
       p16[jobs.copy_stride + j.dst + e] = (_Float16)(vs - (float)h16);
+    }
+  }
+  if (status) {
+    bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) {
+      status[blockIdx.y * gridDim.x + blockIdx.x] = bad ? 1u : 0u;
+      if (blockIdx.x == 0 && blockIdx.y == 0) status[gridDim.x * gridDim.y] = 0u;
     }
   }
 }
@@ -64,7 +77,8 @@ void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st
   jobs.n = n;
   jobs.copy_stride = K.total();
   jobs.with_f16 = 1;
-  hipLaunchKernelGGL(pack_x6_kernel, dim3(64, n), dim3(256), 0, st, d_params, (__bf16*)net->d_packed, jobs);
+  static_assert(kRangeStatusBytes >= (18 * kRangePackBlocks + 1) * sizeof(unsigned), "range record too small");
+  hipLaunchKernelGGL(pack_x6_kernel, dim3(kRangePackBlocks, n), dim3(256), 0, st, d_params, (__bf16*)net->d_packed, jobs, range_status_words(net));
 }
 
 // WAVES = 8: 128-row tiles, two waves per SIMD.  WAVES = 4 (small row counts, fewer tiles than CUs): 64-row tiles, one

@@ -416,11 +416,11 @@ __device__ __forceinline__ void layer_input_lds(f32x4 (&acc)[NTOUT], const float
 
 // ---------------------------------------------------------------------------------------
 // preparing a 32-feature K-group (two 16-feature blocks v0, v1 of raw pre-activations -> activated in
-// place -> Frag3) in six micro-steps: 0, 1 = Philox4x32-10 (five rounds each; even groups only: one call = 16 draws);
+// place -> Frag3) in six micro-steps: 0, 1 = Philox4x32-10 (five rounds each; one call = the group's eight 16-bit draws);
 // 2 .. 5 = register r = k - 2 of both blocks: tanh, dropout, 3-way split (and the predict head's dot).
 // ---------------------------------------------------------------------------------------
 struct PrepBase {
-  unsigned w0, w1, w2, w3;   // Philox counter / output words: one call = sixteen 8-bit draws = a lane's share of TWO 32-groups
+  unsigned w0, w1, w2, w3;   // Philox counter / output words: one call = eight 16-bit draws = a lane's share of one 32-group
   unsigned keep;             // injected masks (kBits) only
 };
 template <typename S>
@@ -441,11 +441,11 @@ __device__ __forceinline__ void philox_rounds5(PrepBase& s, unsigned seed_lo, un
     s.w1 = (unsigned)p1; s.w3 = (unsigned)p0; s.w0 = n0; s.w2 = n2;
   }
 }
-// draw of register r of block b of the 32-group with parity par inside its 64-feature pair: byte r of word 2 par + b
-template <int PAR, int B, int R>
+// draw of register r of block b of the group: index 4 b + r -> half (index & 1) of word (index >> 1)
+template <int B, int R>
 __device__ __forceinline__ bool keep_draw(const PrepBase& s, unsigned thr) {
-  const unsigned w = PAR == 0 ? (B == 0 ? s.w0 : s.w1) : (B == 0 ? s.w2 : s.w3);
-  return ((w >> (8 * R)) & 0xFFu) >= thr;
+  const unsigned w = B == 0 ? (R < 2 ? s.w0 : s.w1) : (R < 2 ? s.w2 : s.w3);
+  return ((R & 1) ? (w >> 16) : (w & 0xFFFFu)) >= thr;
 }
 // A kept activation that is exactly 0 is stashed as FLT_MIN: the backward pass reads "dropped" off h == 0 (no keep-bit
 // stash), and FLT_MIN contributes nothing anywhere (1 - a^2 == 1, products with it underflow).
@@ -461,55 +461,67 @@ __device__ __forceinline__ float tanh_pre(float x, float pre) {
 // wp32: the predict head's 32 weights of this group (LDS) when kDot; the dot is accumulated only if dot_on.
 // pre: tanh_pre's constant for the raw values v0, v1; ld.scale is the dropout scale TIMES S::kActScale.
 // sp (training only, else nullptr): this lane's slot of the group's first feature in the activation stash.
-// FP: the 32-group's index inside its dropout layer; the even group of a pair runs the Philox call, both read it.
-template <typename S, bool kBits, bool kDot, int k, int FP>
+// FP: the 32-group's index inside its dropout layer (the Philox call index).
+// kPack (PINN_PREC_F32X6 on the fused nets): the stash keeps the group as the B fragments just built -- the two fp16 parts of
+// S::kActScale x the activation, 16 B per lane and part -- instead of fp32 values: the backward chain rebuilds the activation
+// from hi + lo (22 bits, what the forward MFMAs used), and the weight-gradient kernel reads ready operands instead of
+// splitting 7.7 GB of fp32 again (round 2: 7.6 VALU instructions per MFMA there).  "Dropped" is still h == 0: a kept
+// activation below 2^-25 / 8 rounds to (0, 0) and is taken for dropped -- about two of the 1e9 activations of a 1e6-row step.
+template <typename S, bool kBits, bool kDot, int k, int FP, bool kPack = false>
 __device__ __forceinline__ void prep_micro(PrepBase& s, f32x4& v0, f32x4& v1, const DropDev& d, const RowCtx& c, const LayerDrop ld, float pre,
                                            int layer, const float* wp32, float& up, bool dot_on, typename S::Frag& out, float* sp = nullptr) {
-  constexpr int fp = FP, par = FP & 1;
+  constexpr int fp = FP;
   if constexpr (k == 0) {
     if (kBits) {
       const unsigned word = d.bits[((long long)c.pass * c.n_rows + c.lrow) * d.words + layer * d.nb + fp];
       const unsigned lo = (word >> (4 * c.kq)) & 0xFu, hi = (word >> (16 + 4 * c.kq)) & 0xFu;
       s.keep = ld.thr == 0 ? 0xFFu : (lo | (hi << 4));
-    } else if constexpr (par == 0) {
+    } else {
       // the counter passes through an empty volatile asm: otherwise hipcc computes every group's first rounds once,
       // outside the pass loop, and keeps them in registers (spills)
       unsigned kq = (unsigned)c.kq;
       asm volatile("" : "+v"(kq));
       s.w0 = (unsigned)c.grow; s.w1 = (unsigned)((unsigned long long)c.grow >> 32);
-      s.w2 = ((unsigned)layer << 16) | ((unsigned)(fp >> 1) << 2) | kq; s.w3 = d.stream + c.pass;
+      s.w2 = ((unsigned)layer << 16) | ((unsigned)fp << 2) | kq; s.w3 = d.stream + c.pass;
       philox_rounds5<0>(s, d.seed_lo, d.seed_hi);
     }
   } else if constexpr (k == 1) {
-    if constexpr (!kBits && par == 0) philox_rounds5<5>(s, d.seed_lo, d.seed_hi);
+    if constexpr (!kBits) philox_rounds5<5>(s, d.seed_lo, d.seed_hi);
   } else if constexpr (k < 6) {
     constexpr int r = k - 2;
     // scale * tanh(x) = scale - 2 scale / (e^{2x} + 1): the dropout / operand scale rides in the tanh's last fma
     const float m2s = -2.0f * ld.scale;
     const float a0 = fmaf(m2s, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v0[r] * pre) + 1.0f), ld.scale);
     const float a1 = fmaf(m2s, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v1[r] * pre) + 1.0f), ld.scale);
-    const bool k0 = kBits ? ((s.keep >> r) & 1u) != 0 : keep_draw<par, 0, r>(s, ld.thr);
-    const bool k1 = kBits ? ((s.keep >> (4 + r)) & 1u) != 0 : keep_draw<par, 1, r>(s, ld.thr);
+    const bool k0 = kBits ? ((s.keep >> r) & 1u) != 0 : keep_draw<0, r>(s, ld.thr);
+    const bool k1 = kBits ? ((s.keep >> (4 + r)) & 1u) != 0 : keep_draw<1, r>(s, ld.thr);
     const float hs0 = k0 ? a0 : 0.0f;                      // the matrix operand: S::kActScale x the activation
     const float hs1 = k1 ? a1 : 0.0f;
     S::template split<r>(hs0, hs1, out);
     float h0 = hs0, h1 = hs1;                              // the activation itself (stash, predict head)
     if constexpr (S::kActScale != 1.0f) {
-      if (sp || kDot) { h0 = hs0 * (1.0f / S::kActScale); h1 = hs1 * (1.0f / S::kActScale); }
+      if ((sp && !kPack) || kDot) { h0 = hs0 * (1.0f / S::kActScale); h1 = hs1 * (1.0f / S::kActScale); }
     }
     // training: the registers keep the value the stash will hold (stored by micro-step 6, behind the step's last DMA)
-    v0[r] = sp ? stash_value(h0, k0) : h0;
-    v1[r] = sp ? stash_value(h1, k1) : h1;
+    if constexpr (!kPack) {
+      v0[r] = sp ? stash_value(h0, k0) : h0;
+      v1[r] = sp ? stash_value(h1, k1) : h1;
+    }
     if (kDot) {
       const float t = fmaf(wp32[4 * c.kq + r], h0, wp32[16 + 4 * c.kq + r] * h1);
       up += dot_on ? t : 0.0f;
     }
   } else {
     if (sp) {
+      if constexpr (kPack) {      // the fragments as they stand: two 16-B stores
+        PINN_STASH_ST(reinterpret_cast<u32x4*>(sp), out.hi);
+        PINN_STASH_ST(reinterpret_cast<u32x4*>(sp + 256), out.lo);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        PINN_STASH_ST(sp + r * 16, v0[r]);
-        PINN_STASH_ST(sp + (16 + r) * 16, v1[r]);
+        for (int r = 0; r < 4; ++r) {
+          PINN_STASH_ST(sp + r * 16, v0[r]);
+          PINN_STASH_ST(sp + (16 + r) * 16, v1[r]);
+        }
       }
     }
   }
@@ -592,10 +604,19 @@ __device__ __forceinline__ void fill_small(float* small, float* w0t, const float
   __syncthreads();
 }
 
+__device__ __forceinline__ int lane_of(const RowCtx& c) { return c.lane; }
+
 // first matrix of the forward slab sequence (the pass after the last one wraps around to it); its row stride is H
 template <int H>
 __device__ __forceinline__ Mat first_mat(const PackLayout& K) {
   return K.nh > 1 ? Mat{(unsigned)K.w(1), clog2(H / 16)} : Mat{(unsigned)K.wv0(), clog2(H / 32)};
+}
+
+// Packed stash (kPack): a 32-feature group of a 16-row tile occupies the same 2 KB the fp32 layout gives it, as
+// [part hi / lo][row n][kq][8 x f16]: element 2 r + b of (n, kq) = feature 16 b + 4 kq + r of the group -- the chain's B
+// fragment, 16 B per lane and part.  This lane's slot of group 0 (group g: + 512 g floats; part lo: + 256 floats):
+__device__ __forceinline__ float* packed_ptr(float* base, long long t16, int F, int lane) {
+  return base + t16 * F * 16 + (lane & 15) * 16 + (lane >> 4) * 4;
 }
 
 // stash of one 16-row tile: activations and d(pre-activations) as [layer][T16][F][16] fp32 (the fp32 kernels' layout)
@@ -609,6 +630,12 @@ struct StashX {
   __device__ __forceinline__ float* dact(int layer, int H_, int lane) const {
     return tiled_ptr(dh + (long long)layer * t16_total * H_ * 16, t16, H_, lane);
   }
+  __device__ __forceinline__ float* actp(int layer, int H_, int lane) const {     // packed forms
+    return packed_ptr(h + (long long)layer * t16_total * H_ * 16, t16, H_, lane);
+  }
+  __device__ __forceinline__ float* dactp(int layer, int H_, int lane) const {
+    return packed_ptr(dh + (long long)layer * t16_total * H_ * 16, t16, H_, lane);
+  }
 };
 
 // One forward pass for this wave's 16 rows in arithmetic scheme S (X3: the kernels' forward passes; X6 kept for
@@ -616,12 +643,15 @@ struct StashX {
 // weight stream arrives and leaves positioned on the forward sequence's first matrix.  `smallp` holds the biases of the
 // matrix layers (b_1.., bv_0, bv_1) TIMES S::kAccScale (the kernels scale them when they fill the LDS), b_0 and the head
 // vectors as they are.
-template <typename S, int H, bool kBits, bool TRAIN = false, int WAVES = 8>
+template <typename S, int H, bool kBits, bool TRAIN = false, int WAVES = 8, bool kPack = false>
 __device__ __forceinline__ void forward_pass(const float* w0t, const float* smallp, const ParamLayout& L, typename S::Pipe& pipe,
                                              const DropDev& d, const RowCtx& c, const f32x4& xa, const f32x4& xb, float& u, float& z,
                                              const StashX* sx = nullptr) {
+  static_assert(!kPack || (TRAIN && S::kCopies == 2), "the packed stash holds scheme X3's fragments");
   constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32, NC = S::kCopies;
-  constexpr int kSt = TRAIN ? 8 : 0;      // stash stores per prepared group (behind the step's last DMA)
+  constexpr int kSt = TRAIN ? (kPack ? 2 : 8) : 0;      // stash stores per prepared group (behind the step's last DMA)
+  auto act_ptr = [&](int layer) -> float* { return kPack ? sx->actp(layer, H, lane_of(c)) : sx->act(layer, H, lane_of(c)); };
+  auto v1_ptr = [&]() -> float* { return kPack ? packed_ptr(sx->v1, sx->t16, H / 2, lane_of(c)) : tiled_ptr(sx->v1, sx->t16, H / 2, lane_of(c)); };
   using Frag = typename S::Frag;
   const int lane = c.lane, kq = c.kq;
   const SmallLayout SL{L.H, L.nh};
@@ -638,8 +668,8 @@ __device__ __forceinline__ void forward_pass(const float* w0t, const float* smal
   layer_input_lds<NT>(h, w0t, smallp + SL.b(0), xa, xb, lane);      // 8 -> H in exact fp32 (K = 8)
   {   // group 0 of the first matrix layer's input: nothing to hide it under
     const LayerDrop ld0 = drop_of(0);
-    float* sp = TRAIN ? sx->act(0, H, lane) : nullptr;
-    static_for<7>([&](auto kc) { prep_micro<S, kBits, true, decltype(kc)::value, 0>(st, h[0], h[1], d, c, ld0, kPre0, 0, wp, up, ll == 0, st.buf[0], sp); });
+    float* sp = TRAIN ? act_ptr(0) : nullptr;
+    static_for<7>([&](auto kc) { prep_micro<S, kBits, true, decltype(kc)::value, 0, kPack>(st, h[0], h[1], d, c, ld0, kPre0, 0, wp, up, ll == 0, st.buf[0], sp); });
   }
 #pragma unroll 1
   for (int l = 1; l < L.nh; ++l) {
@@ -649,18 +679,18 @@ __device__ __forceinline__ void forward_pass(const float* w0t, const float* smal
     const float pre_in = l == 1 ? kPre0 : kPreS;                    // layer 0's output comes from the exact-fp32 input layer
     const bool last = l == ll;
     const Mat mine{(unsigned)K.w(l), clog2(H / 16)}, next = last ? m_v0 : Mat{(unsigned)K.w(l + 1), clog2(H / 16)};
-    float* sp_in = TRAIN ? sx->act(l - 1, H, lane) : nullptr;
-    float* sp_out = TRAIN ? sx->act(l, H, lane) : nullptr;
+    float* sp_in = TRAIN ? act_ptr(l - 1) : nullptr;
+    float* sp_out = TRAIN ? act_ptr(l) : nullptr;
     static_assert(NP % 2 == 0 && (NP / 2) % 2 == 0, "the forward layers keep the fragment buffer parity");
     layer_x6<S, 0, NP, NT, KPW, KPW, NC * H / 16, NC * H / 16, true, WAVES, kSt, kSt, clog2(H / 16)>(
         acc, pipe, mine, next, lane, st,
         [&](auto gc, auto kc, Frag& out) {
           constexpr int g = decltype(gc)::value;
-          prep_micro<S, kBits, false, decltype(kc)::value, g>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, pre_in, l - 1, wp, up, false, out,
-                                                             TRAIN ? sp_in + 32 * g * 16 : nullptr);
+          prep_micro<S, kBits, false, decltype(kc)::value, g, kPack>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, pre_in, l - 1, wp, up, false, out,
+                                                                    TRAIN ? sp_in + 32 * g * 16 : nullptr);
         },
         [&](auto kc, Frag& out) {
-          prep_micro<S, kBits, true, decltype(kc)::value, 0>(st, acc[0], acc[1], d, c, ld_out, kPreS, l, wp, up, last, out, sp_out);
+          prep_micro<S, kBits, true, decltype(kc)::value, 0, kPack>(st, acc[0], acc[1], d, c, ld_out, kPreS, l, wp, up, last, out, sp_out);
         });
 #pragma unroll
     for (int t = 0; t < NT; ++t) h[t] = acc[t];
@@ -671,17 +701,17 @@ __device__ __forceinline__ void forward_pass(const float* w0t, const float* smal
   {
     const LayerDrop ld_in = drop_of(ll), ld_out = drop_of(L.nh);
     const float pre_in = ll == 0 ? kPre0 : kPreS;
-    float* sp_in = TRAIN ? sx->act(ll, H, lane) : nullptr;
-    float* sp_out = TRAIN ? tiled_ptr(sx->v1, sx->t16, H / 2, lane) : nullptr;
+    float* sp_in = TRAIN ? act_ptr(ll) : nullptr;
+    float* sp_out = TRAIN ? v1_ptr() : nullptr;
     layer_x6<S, 0, NP, NT2, KPW, KPV1, NC * H / 32, NC * H / 64, true, WAVES, kSt, kSt, (WAVES <= H / 32 ? clog2(H / 32) : -1)>(
         v1, pipe, m_v0, m_v1, lane, st,
         [&](auto gc, auto kc, Frag& out) {
           constexpr int g = decltype(gc)::value;
-          prep_micro<S, kBits, true, decltype(kc)::value, g>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, pre_in, ll, wp + 32 * g, up, true, out,
-                                                            TRAIN ? sp_in + 32 * g * 16 : nullptr);
+          prep_micro<S, kBits, true, decltype(kc)::value, g, kPack>(st, h[2 * g], h[2 * g + 1], d, c, ld_in, pre_in, ll, wp + 32 * g, up, true, out,
+                                                                   TRAIN ? sp_in + 32 * g * 16 : nullptr);
         },
         [&](auto kc, Frag& out) {
-          prep_micro<S, kBits, false, decltype(kc)::value, 0>(st, v1[0], v1[1], d, c, ld_out, kPreS, L.nh, wp, up, false, out, sp_out);
+          prep_micro<S, kBits, false, decltype(kc)::value, 0, kPack>(st, v1[0], v1[1], d, c, ld_out, kPreS, L.nh, wp, up, false, out, sp_out);
         });
   }
   u = sum_kq(up) + smallp[SL.bp()];
@@ -689,11 +719,11 @@ __device__ __forceinline__ void forward_pass(const float* w0t, const float* smal
   bias_blocks<NT4>(v2, smallp + SL.bv1(), kq);
   {
     const LayerDrop ld_in = drop_of(L.nh);
-    float* sp_in = TRAIN ? tiled_ptr(sx->v1, sx->t16, H / 2, lane) : nullptr;
+    float* sp_in = TRAIN ? v1_ptr() : nullptr;
     auto prep_in = [&](auto gc, auto kc, Frag& out) {
       constexpr int g = decltype(gc)::value;
-      prep_micro<S, kBits, false, decltype(kc)::value, g>(st, v1[2 * g], v1[2 * g + 1], d, c, ld_in, kPreS, L.nh, wp, up, false, out,
-                                                         TRAIN ? sp_in + 32 * g * 16 : nullptr);
+      prep_micro<S, kBits, false, decltype(kc)::value, g, kPack>(st, v1[2 * g], v1[2 * g + 1], d, c, ld_in, kPreS, L.nh, wp, up, false, out,
+                                                                TRAIN ? sp_in + 32 * g * 16 : nullptr);
     };
     layer_x6<S, 0, NP / 2, NT4, KPV1, KPW, NC * H / 64, NC * H / 16, false, WAVES, kSt, 0>(v2, pipe, m_v1, first_mat<H>(K), lane, st, prep_in,
                                                                                           [&](auto, Frag&) {});

@@ -164,9 +164,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
     for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
-  float bsum[TI], vq[TJ], vr[TI];
+  double bsum[TI];        // (float64: a slice adds thousands of rows one after the other, where torch sums pairwise)
+  float vq[TJ], vr[TI];
 #pragma unroll
-  for (int ti = 0; ti < TI; ++ti) { bsum[ti] = 0.f; vr[ti] = 0.f; }
+  for (int ti = 0; ti < TI; ++ti) { bsum[ti] = 0.0; vr[ti] = 0.f; }
 #pragma unroll
   for (int tj = 0; tj < TJ; ++tj) vq[tj] = 0.f;
 
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-        for (int sg = 0; sg < 2; ++sg) bsum[ti] += (cur.a[ti][sg][0] + cur.a[ti][sg][1]) + (cur.a[ti][sg][2] + cur.a[ti][sg][3]);
+        for (int sg = 0; sg < 2; ++sg) bsum[ti] += (double)((cur.a[ti][sg][0] + cur.a[ti][sg][1]) + (cur.a[ti][sg][2] + cur.a[ti][sg][3]));
       if (a.dvr) {
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_x_kernel(WgradArgs a) {
   if (row_sums) {
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) {
-      const float b = bsum[ti] + __shfl_xor(bsum[ti], 32, 64);
+      const float b = (float)(bsum[ti] + __shfl_xor(bsum[ti], 32, 64));
       if (hh == 0) a.db[so + i0 + ti * 32 + i] = b;
       if (a.dvr) {
         const float v = vr[ti] + __shfl_xor(vr[ti], 32, 64);
@@ -340,9 +341,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_d_kernel(WgradArgs a) {
     for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
-  float bsum[TI];
+  double bsum[TI];
 #pragma unroll
-  for (int ti = 0; ti < TI; ++ti) bsum[ti] = 0.f;
+  for (int ti = 0; ti < TI; ++ti) bsum[ti] = 0.0;
 
   const int slice = blockIdx.x;
   const long long per = (a.t16 + a.n_slices - 1) / a.n_slices;
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_d_kernel(WgradArgs a) {
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-          for (int sg = 0; sg < 2; ++sg) bsum[ti] += (cur.a[ti][sg][0] + cur.a[ti][sg][1]) + (cur.a[ti][sg][2] + cur.a[ti][sg][3]);
+          for (int sg = 0; sg < 2; ++sg) bsum[ti] += (double)((cur.a[ti][sg][0] + cur.a[ti][sg][1]) + (cur.a[ti][sg][2] + cur.a[ti][sg][3]));
       }
       if constexpr (NS == kF16S) {
         PartsP pa[TI];
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_d_kernel(WgradArgs a) {
   if (row_sums) {
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) {
-      const float b = bsum[ti] + __shfl_xor(bsum[ti], 32, 64);
+      const float b = (float)(bsum[ti] + __shfl_xor(bsum[ti], 32, 64));
       if (hh == 0) a.db[so + i0 + ti * 32 + i] = b;
     }
   }

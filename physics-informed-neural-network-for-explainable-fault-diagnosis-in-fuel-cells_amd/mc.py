@@ -28,6 +28,8 @@ def get_MC_samples(network, X, x_scal, mc_times=64, dropout=0.6, device_outputs=
         network.dnn.train()
         row_offset = network.row_offset if X.shape[0] == network.n_local else 0
         pm, au, eu = network.mc_dropout(X, mc_times, row_offset=row_offset)
+        if not device_outputs:
+            network.dnn.check_range()          # (the host waits for the results here anyway)
         out = (pm, au, eu) if device_outputs else (pm.cpu().numpy(), au.cpu().numpy(), eu.cpu().numpy())
     finally:
         for name, module in network.dnn.named_modules():

@@ -126,6 +126,18 @@ class DNN(torch.nn.Module):
             self._packed = torch.empty(nbytes, dtype=torch.uint8, device=_device())
         self._net = _lib.Net(self.n_in, self.hidden, self.n_hidden, codes[precision], self._packed.data_ptr())
 
+    def check_range(self):
+        """Raise PinnRangeError when the last launches met a weight (or, in training, a gradient) outside the domain of the
+        split-operand precisions -- |w| >= 1023.5 in a hidden or variance-head matrix, which the fp32 reference (01:389-438)
+        computes without trouble.  Synchronises the stream: called where the host waits anyway (log lines, results)."""
+        rc = self._lib.pinn_net_range_status(ctypes.byref(self._net), _stream())
+        if rc == _lib.E_RANGE:
+            raise _lib.PinnRangeError(
+                "a weight or gradient left the range of precision %r (|w| must stay below 1023.5 in the hidden and variance-head "
+                "matrices); the outputs of the last calls are inf / NaN there.  dnn.set_precision('fp32') has no such limit%s"
+                % (self.precision, "" if self.hidden <= 256 else " but does not support this width"))
+        _lib.check(rc, "pinn_net_range_status")
+
     # -- flat buffer <-> Parameter aliasing ------------------------------------------------
     def flat_params(self):
         """The flat parameter buffer; re-gathers a Parameter that user code re-pointed elsewhere."""
@@ -393,10 +405,12 @@ class PhysicsInformedNN():
                                               lr, step, _stream())
                 _lib.check(rc, "pinn_adam_step")
             if epoch % 1000 == 0 and loss_sums is not None:
+                self.dnn.check_range()
                 ls = _dp.allreduce_sums(loss_sums.clone(), self._group).cpu().numpy()      # fp64, only when a line is printed
                 lr_next = 0.01 * 0.8 ** ((epoch + 1) // 1000)
                 self._log(f' {epoch:5d}  | {(ls[0] + 0.01 * ls[1]) / n_norm:10.3e} | {ls[2] / n_norm:10.3e} | {lr_next:8.1e}')
         if loss_sums is not None:
+            self.dnn.check_range()
             ls = _dp.allreduce_sums(loss_sums.clone(), self._group).cpu().numpy()
             self.last_loss = (ls[0] + 0.01 * ls[1]) / n_norm
             self._log(f'DNN training done, final loss: {self.last_loss:.3e}')
@@ -521,6 +535,7 @@ class PhysicsInformedNN():
         (The reference's discarded `net_f_V` call, 01:1407, is not run.)"""
         x = self._dev_rows(X)
         u, log_var = self.net_u(x)
+        self.dnn.check_range()
         return u.detach().cpu().numpy(), log_var.detach().cpu().numpy()
 
     # ------------------------------------------------------------------ MC-dropout (used by mc.get_MC_samples)

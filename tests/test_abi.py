@@ -62,6 +62,48 @@ def test_host_only_entry_points(lib):
     assert ctypes.sizeof(_lib.Dropout) == 4 + 36 + 8 + 4 + 4 + 8 + 8   # incl. padding before row_offset
 
 
+def test_null_workspace_and_buffer_pointers_are_argument_errors(lib):
+    """Every entry point that takes a workspace / stash / output pointer returns PINN_E_ARG (-1) for NULL before it touches
+    the GPU (the checks run on the host, so this needs no device), and PINN_E_WORKSPACE (-3) for a workspace that is too
+    small: a kernel is never handed a pointer the entry point has not seen to be non-NULL and large enough.  (Round 2's
+    scratch ablation builds faulted on address nil with a stash pointer their own edit had nulled, gpurun_out/ab2.txt.)"""
+    from pinn_amd import _lib
+    aff = _lib.Affine()
+    one = ctypes.c_void_p(0x1000)          # a non-NULL address that is never dereferenced: every call below fails on the host
+    E_ARG, E_WS = -1, -3
+    # residual pass: sums requested without a workspace; workspace too small
+    assert lib.pinn_residuals(one, one, one, ctypes.byref(aff), one, _lib.RES_ALL, 10, None, 0, one, None, 0, None) == E_ARG
+    assert lib.pinn_residuals(one, one, one, ctypes.byref(aff), one, _lib.RES_ALL, 10, None, 0, one, one, 16, None) == E_WS
+    assert lib.pinn_residuals(None, one, one, ctypes.byref(aff), one, _lib.RES_ALL, 10, None, 0, None, None, 0, None) == E_ARG
+    assert lib.pinn_residuals_cached(one, ctypes.byref(aff), one, _lib.RES_T, 10, one, None, 0, None) == E_ARG
+    assert lib.pinn_residuals_cached(one, ctypes.byref(aff), one, _lib.RES_T, 10, one, one, 16, None) == E_WS
+    assert lib.pinn_residuals_cached(None, ctypes.byref(aff), one, _lib.RES_T, 10, one, one, 1 << 20, None) == E_ARG
+    assert lib.pinn_residuals_prepare(one, None, None, ctypes.byref(aff), one, _lib.RES_T, 10, None, None) == E_ARG
+    assert lib.pinn_lambda_stage_run(_lib.STAGE_THERMAL, _lib.RES_T, one, None, None, ctypes.byref(aff), 10, 1.0, 0.8, 1000, 0, 5, one, one, one,
+                                     None, 1000, None, None, 0, None) == E_ARG
+    assert lib.pinn_lambda_stage_run(_lib.STAGE_THERMAL, _lib.RES_T, one, None, None, ctypes.byref(aff), 10, 1.0, 0.8, 1000, 0, 5, one, one, one,
+                                     None, 1000, None, one, 8, None) == E_WS
+    assert lib.pinn_lambda_step(_lib.STAGE_THERMAL, None, 10, 1.0, 0.1, 1, one, one, one, None) == E_ARG
+    assert lib.pinn_net_f_t(one, one, None, None, ctypes.byref(aff), one, 10, None, one, one, None) == E_ARG
+    # network entry points: NULL parameter / row / output / workspace / packed-weight pointers
+    net = _lib.Net(8, 256, 3)
+    assert lib.pinn_mlp_forward(ctypes.byref(net), one, one, 10, None, None, one, None) == E_ARG
+    assert lib.pinn_mlp_forward(ctypes.byref(net), one, None, 10, None, one, one, None) == E_ARG
+    d = _lib.Dropout(); d.mode = _lib.DROP_PHILOX
+    assert lib.pinn_mc_dropout(ctypes.byref(net), one, one, 10, ctypes.byref(d), 4, one, None, one, None) == E_ARG
+    assert lib.pinn_mlp_train_grads(ctypes.byref(net), one, one, one, 10, 10, None, one, one, None, 1 << 30, None) == E_ARG
+    assert lib.pinn_mlp_train_grads(ctypes.byref(net), one, one, one, 10, 10, None, ctypes.c_void_p(0x1000), one, ctypes.c_void_p(0x2000), 16, None) == E_WS
+    assert lib.pinn_mlp_train_grads(ctypes.byref(net), one, one, one, 10, 10, None, ctypes.c_void_p(0x1004), one, ctypes.c_void_p(0x2000), 1 << 30, None) == E_ARG   # alignment
+    for prec in (_lib.PREC_BF16, _lib.PREC_F32X6, _lib.PREC_F32X6_G6):
+        split = _lib.Net(8, 256, 3, prec, None)           # a split-operand precision without its packed-weight scratch
+        assert lib.pinn_mlp_forward(ctypes.byref(split), one, one, 10, None, one, one, None) == E_ARG
+        assert lib.pinn_mlp_train_grads(ctypes.byref(split), one, one, one, 10, 10, None, one, one, one, 1 << 30, None) == E_ARG
+    d.mode = _lib.DROP_BITS            # injected masks without the mask buffer
+    assert lib.pinn_mlp_forward(ctypes.byref(net), one, one, 10, ctypes.byref(d), one, one, None) == E_ARG
+    assert lib.pinn_adam_step(one, one, None, one, 10, 0.01, 1, None) == E_ARG
+    assert lib.pinn_results_assemble(one, one, ctypes.byref(aff), 0.0, 1.0, 200, None, 0, one, one, one, one, 10, None, 10, None, None) == E_ARG
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "physics-informed-neural-network-for-explainable-fault-diagnosis-in-fuel-cells_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -4,7 +4,9 @@
   32-double stage sums pushed through `dp.allreduce_*` with the world-size guard bypassed (force=True) -- the buffers
   must come back bit-identical and `dp.backend()` must say nccl;
 * world_size 2 on ONE card (gloo carries the collectives; RCCL needs one GPU per rank): `PhysicsInformedNN.train_dnn`
-  (full batch and minibatches over UNEVEN shards -- the schedule that used to deadlock), `train_lambda` (both variants),
+  (full batch and minibatches over UNEVEN shards, 400 and 401 rows with 200-row batches: the longer shard dictates three
+  batches per epoch and the shorter one's third batch has no rows -- the branch of train_dnn that steps the dropout stream,
+  contributes a zero gradient and still joins the all-reduce; round 2's sizes never reached it), `train_lambda` (both variants),
   `train_thermal / hydrogen / oxygen` on row shards: parameters bit-identical across ranks and equal, within the fp32
   reduction-order tolerance, to one process on all rows.
 """
@@ -18,7 +20,7 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
-N, BATCH, SEED = 1001, 200, 3
+N, BATCH, SEED = 801, 200, 3       # shards of 400 and 401 rows: rank 0's third 200-row batch is EMPTY (zero gradient, same collective)
 LAYERS = [8, 256, 256, 256, 1]
 
 

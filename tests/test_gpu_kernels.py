@@ -122,6 +122,41 @@ def test_mc_dropout_philox_statistics(lib):
     assert abs(np.mean(o[1]) / np.mean(au2) - 1) < 0.05
 
 
+def test_mc_dropout_T2000_band_vs_bernoulli(lib):
+    """SURVEY 8(c) G8 at the reference's real setting (mc_times = 2000, dropout 0.4, 01:2156-2158): the uncertainty
+    columns of the on-chip Philox stream against the oracle on torch-bernoulli masks (what the reference draws).
+    16 384 rows go through the device; the oracle runs the first 1024 of them.  Per row both estimates carry a relative
+    Monte-Carlo error of 1 / sqrt(2 T) = 1.6 %; the means over the 1024 common rows must agree within 3 standard errors
+    of their difference.  A systematic gain of the stochastic passes shows here, in a_u above all (its per-row Monte-Carlo
+    error is 50x smaller than e_u's): masks with round 2's 8-bit keep probability 154/256 under the 1 / 0.6 scale, run through
+    the oracle on 384 rows, put mean a_u 3.3 standard errors off (~5 at 1024 rows) and mean e_u +0.1 %; the 16-bit stream
+    sits at 0.6 / -1.9 there (CPU emulation, both against the same bernoulli masks)."""
+    import hip_helpers as hh
+    from pinn_amd import _lib, synth
+    H, nh, N, NREF, T, p = 256, 3, 16384, 1024, 2000, 0.4
+    P = O.init_params([8, H, H, H, 1], seed=3)
+    x = synth.make_dataset(N, (), seed=4)[0]
+    out = torch.empty(3, N, device=hh.dev())
+    net = hh.make_net(lib, H, nh, 2)
+    d = hh.dropout_struct(1, [p] * 4, seed=2024, stream_id=1, row_offset=0)
+    fp, xd = hh.flat_params(P, H, nh).to(hh.dev()), x.to(hh.dev())
+    _lib.check(lib.pinn_mc_dropout(ctypes.byref(net), hh.ptr(fp), hh.ptr(xd), N,
+                                   ctypes.byref(d), T, hh.ptr(out[0]), hh.ptr(out[1]), hh.ptr(out[2]), hh.stream()), "mc")
+    o = out.cpu().numpy()
+    gen = torch.Generator().manual_seed(7)
+    mk = lambda t: [(torch.rand(NREF, w, generator=gen) >= p).numpy() for w in (H, H, H, H // 2)]
+    pm, au, eu = O.mc_dropout(P, x[:NREF], p, T, mk)
+    np.testing.assert_allclose(o[0][:NREF], pm, rtol=RTOL, atol=ATOL)
+    for name, dev_col, ref in (("e_u", o[2], eu), ("a_u", o[1], au)):
+        diff = dev_col[:NREF].astype(np.float64) - ref.astype(np.float64)
+        se = diff.std(ddof=1) / np.sqrt(NREF)
+        z = diff.mean() / se
+        assert abs(z) < 3.0, (name, z, diff.mean() / ref.mean())
+        assert se / ref.mean() < 2e-3, (name, se / ref.mean())          # the band is tight enough to see a 0.8 % gain
+        # and the 15 360 rows the oracle did not run look like the ones it did (same stream, same statistics)
+        assert abs(dev_col[NREF:].mean() / dev_col[:NREF].mean() - 1) < 0.1
+
+
 @pytest.mark.parametrize("si", [0, 1])
 def test_residuals_golden(lib, si):
     """G5: every tuple element of net_f_V/_T_simple/_H/_O + d mean(f^2)/d lambda on branch-edge rows."""
@@ -169,6 +204,89 @@ def test_residuals_golden(lib, si):
         want = g["s%d.Vn.grad" % si][L(ln)]
         got = -2.0 * 5.0 * aff.vn_scale * s[S["YV_D1"] + k] / N
         assert abs(got - want) <= 1e-4 * abs(want) + 1e-9, (ln, got, want)
+
+
+def test_residuals_surface_nan_like_the_reference(lib):
+    """SURVEY section 5 / 01:758-761: a row with i >= lambda_3 (I > ~657 A at the initial il = 2.434) takes log(1 - i/il) of a
+    non-positive number.  The reference neither masks nor clamps it: f_V, V_conc and V_est are NaN on that row, the stage
+    loss and every gradient are NaN, Adam makes the three live parameters NaN and torch.clamp keeps them NaN.  The fused
+    kernels must show the SAME NaN pattern -- per-row columns, sums, cached sums, the parameters after a persistent stage
+    run -- and leave every other row / stage untouched (fminf / fmaxf clamps would swallow a NaN: clamp_t)."""
+    import hip_helpers as hh
+    from pinn_amd import _lib, synth
+    N, hot = 2000, [3, 777, 1999]
+    ds = synth.make_dataset(N, (), seed=8)
+    mn, sc = O.scaler_affine(ds[4])
+    ymn, ysc = O.scaler_affine(ds[5])
+    xn = ds[0].clone()
+    xn[hot, 0] = float(700.0 * sc[0] + mn[0])                  # normalised value of I = 700 A
+    real = torch.from_numpy(O.denorm(xn.numpy(), mn, sc))
+    assert all(abs(float(real[r, 0]) - 700.0) < 1e-2 for r in hot)
+    u = (ds[1] + 0.01).reshape(-1, 1).contiguous()
+    y = ds[1].reshape(-1).contiguous()
+    lam = O.init_lambdas()
+    want = O.net_f_V(real, u, ymn, ysc, lam)
+    aff = hh.affine_struct(ds[4], ds[5])
+    xd, ud, yd = xn.to(hh.dev()), u.reshape(-1).to(hh.dev()), y.to(hh.dev())
+    lam0 = torch.tensor([O.LAMBDA_INIT[n] for n in O.LAMBDA_NAMES], dtype=torch.float32)
+    lamd = lam0.to(hh.dev())
+    cols = torch.zeros(_lib.NCOLS, N, device=hh.dev())
+    sums = torch.zeros(_lib.NSUMS, dtype=torch.float64, device=hh.dev())
+    wb = lib.pinn_residuals_workspace_bytes()
+    work = torch.empty(wb, dtype=torch.uint8, device=hh.dev())
+    _lib.check(lib.pinn_residuals(hh.ptr(xd), hh.ptr(ud), hh.ptr(yd), ctypes.byref(aff), hh.ptr(lamd), _lib.RES_ALL, N, hh.ptr(cols), N,
+                                  hh.ptr(sums), hh.ptr(work), wb, hh.stream()), "residuals")
+    c, s = cols.cpu().numpy(), sums.cpu().numpy()
+    C, S = _lib.C, _lib.S
+    for j, cn in ((0, "FV"), (1, "VACT"), (2, "VOHM"), (3, "VCONC"), (4, "ENERNST"), (5, "VEST5"), (6, "I"), (8, "VOUT5")):
+        w = want[j].detach().numpy().reshape(-1)
+        assert np.array_equal(np.isnan(c[C[cn]]), np.isnan(w)), cn
+        ok = ~np.isnan(w)
+        np.testing.assert_allclose(c[C[cn]][ok], w[ok], rtol=RTOL, atol=ATOL * max(1.0, np.abs(w[ok]).max()), err_msg=cn)
+    nan_rows = np.where(np.isnan(c[C["FV"]]))[0].tolist()
+    assert nan_rows == hot, nan_rows
+    v_sums = ["FV2", "FV_D1", "FV_D2", "FV_D3", "YV2", "YV_D1", "YV_D2", "YV_D3"]
+    assert all(np.isnan(s[S[k]]) for k in v_sums), {k: s[S[k]] for k in v_sums}
+    assert all(np.isfinite(s[S[k]]) for k in ("YU2", "FT2", "FH2", "FO2", "FT_D1", "FH_D1", "FO_D1"))
+    # the cached form of the same pass
+    cache = torch.empty(6 * N, dtype=torch.float32, device=hh.dev())
+    _lib.check(lib.pinn_residuals_prepare(hh.ptr(xd), hh.ptr(ud), hh.ptr(yd), ctypes.byref(aff), hh.ptr(lamd), _lib.RES_V, N, hh.ptr(cache),
+                                          hh.stream()), "prepare")
+    s2 = torch.zeros(_lib.NSUMS, dtype=torch.float64, device=hh.dev())
+    _lib.check(lib.pinn_residuals_cached(hh.ptr(cache), ctypes.byref(aff), hh.ptr(lamd), _lib.RES_V, N, hh.ptr(s2), hh.ptr(work), wb, hh.stream()),
+               "cached")
+    s2 = s2.cpu().numpy()
+    assert all(np.isnan(s2[S[k]]) for k in v_sums) and np.isfinite(s2[S["YU2"]])
+    # a whole stage, both variants, persistent kernel and iterated kernels: the parameters end up as the reference's do
+    for stage, dnn_para in ((_lib.STAGE_LAMBDA_PM, False), (_lib.STAGE_LAMBDA_F, True)):
+        lo, _ = O.run_stage("lambda", 3, real, O.init_lambdas(), y=y.reshape(-1, 1), u_eval=u, y_min=ymn, y_scale=ysc, u_scal=ds[5],
+                            dnn_para=dnn_para)
+        want_nan = [bool(torch.isnan(lo[n]).any()) for n in O.LAMBDA_NAMES]
+        assert want_nan[:4] == [True, True, True, False]
+        lam_p = lam0.clone().to(hh.dev())
+        adam = torch.zeros(2 * _lib.NLAMBDA, device=hh.dev())
+        loss = torch.zeros(2, device=hh.dev())
+        swb = lib.pinn_lambda_stage_workspace_bytes(N)
+        swork = torch.empty(swb, dtype=torch.uint8, device=hh.dev())
+        _lib.check(lib.pinn_lambda_stage_run(stage, _lib.RES_V, hh.ptr(xd), hh.ptr(ud), hh.ptr(yd), ctypes.byref(aff), N, 1e-3, 0.8, 1000, 0, 3,
+                                             hh.ptr(lam_p), hh.ptr(adam), hh.ptr(loss), None, 1000, None, hh.ptr(swork), swb, hh.stream()), "stage_run")
+        got = lam_p.cpu().numpy()
+        assert np.isnan(got).tolist() == want_nan, (stage, got)
+        assert np.array_equal(got[3:], lam0.numpy()[3:]) and np.isnan(loss.cpu().numpy()).all()
+        lam_i = lam0.clone().to(hh.dev())
+        adam.zero_()
+        for it in range(3):
+            _lib.check(lib.pinn_residuals(hh.ptr(xd), hh.ptr(ud), hh.ptr(yd), ctypes.byref(aff), hh.ptr(lam_i), _lib.RES_V, N, None, 0,
+                                          hh.ptr(sums), hh.ptr(work), wb, hh.stream()), "residuals")
+            _lib.check(lib.pinn_lambda_step(stage, hh.ptr(sums), N, aff.vn_scale, 1e-3, it + 1, hh.ptr(lam_i), hh.ptr(adam), hh.ptr(loss),
+                                            hh.stream()), "lambda_step")
+        assert np.isnan(lam_i.cpu().numpy()).tolist() == want_nan
+    # a NaN oxygen threshold parameter: torch.clamp(target, 1.05, 15) stays NaN, so does the residual
+    lam_o = lam0.clone()
+    lam_o[O.LAMBDA_NAMES.index("lambda_O2")] = float("nan")
+    _lib.check(lib.pinn_residuals(hh.ptr(ds[0].to(hh.dev())), None, None, ctypes.byref(aff), hh.ptr(lam_o.to(hh.dev())), _lib.RES_O, N, hh.ptr(cols), N,
+                                  hh.ptr(sums), hh.ptr(work), wb, hh.stream()), "residuals")
+    assert torch.isnan(cols[C["FO"]]).all() and torch.isnan(cols[C["TGTO"]]).all() and np.isnan(sums.cpu().numpy()[S["FO2"]])
 
 
 def test_residuals_partial_flags_and_determinism(lib):

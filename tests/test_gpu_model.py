@@ -249,13 +249,58 @@ def test_checkpoint_roundtrip(tmp_path):
         pinn_amd.load_checkpoint(c, path)
 
 
+def _adam_noise_bands(P0, x, y, bounds, epochs, mask_fn, lr, n_noise=12, seed=0):
+    """Float64 referee for a train_dnn trajectory (01:948-955) and, per element, what fp32-grade gradient noise does to it.
+
+    Adam divides by sqrt(v) + eps: an element whose gradient is near eps turns ANY rounding noise of the gradient into a
+    visible step, so a fixed band around a reference trajectory (or a comparison of two largest errors) measures luck, not
+    arithmetic.  Here the float64 trajectory is re-run `n_noise` times with every gradient tensor perturbed by Gaussian noise
+    of the rms the REFERENCE's own fp32 arithmetic shows against float64 on that tensor at that step (torch fp32 autograd at
+    the same weights: nothing tuned); the spread of the final weights is the band an fp32-accurate implementation may use,
+    element by element.  Returns (w64, w32, spread): float64 trajectory, the fp32 oracle's, per-element rms deviation."""
+    P64 = [p.double().clone() for p in P0]
+    P32 = [p.clone() for p in P0]
+    noisy = [[p.double().clone() for p in P0] for _ in range(n_noise)]
+    opt64, opt32, optn = O.AdamState(P64), O.AdamState(P32), [O.AdamState(q) for q in noisy]
+    gen = torch.Generator().manual_seed(seed)
+    x64, y64 = x.double(), y.double()
+    step = 0
+    for epoch in range(epochs):
+        for s, e in bounds:
+            step += 1
+            masks, pl = mask_fn(step, s, e)
+            _, _, g64, _, _ = O.nll_loss_and_grads(P64, x64[s:e], y64[s:e], pl, masks)
+            # the reference's arithmetic at the same weights: its error on each tensor sets that tensor's noise level
+            _, _, g32r, _, _ = O.nll_loss_and_grads([p.float() for p in P64], x[s:e], y[s:e], pl, masks)
+            sig = [float((a.double() - b).pow(2).mean().sqrt()) for a, b in zip(g32r, g64)]
+            for q, on in zip(noisy, optn):
+                _, _, gq, _, _ = O.nll_loss_and_grads(q, x64[s:e], y64[s:e], pl, masks)
+                on.step(q, [g + sg * torch.randn(g.shape, generator=gen, dtype=torch.float64) for g, sg in zip(gq, sig)], lr)
+            opt64.step(P64, g64, lr)
+            _, _, g32, _, _ = O.nll_loss_and_grads(P32, x[s:e], y[s:e], pl, masks)
+            opt32.step(P32, g32, lr)
+    spread = [torch.stack([q[i] - P64[i] for q in noisy]).pow(2).mean(0).sqrt().numpy() for i in range(len(P0))]
+    return [p.numpy() for p in P64], [p.double().numpy() for p in P32], spread
+
+
 @pytest.mark.parametrize("batch_size", [None, 256])
 def test_train_dnn_philox_masks_vs_oracle(batch_size):
     """train_dnn with the on-chip Philox masks, full batch and minibatches (BASELINE config 4's shape in miniature): the
     oracle replays the same masks (stream = optimizer step, row offset = first row of the batch) and takes the same Adam
-    steps; a minibatch is normalised by its own row count (01:949-955 applied per batch)."""
+    steps; a minibatch is normalised by its own row count (01:949-955 applied per batch).
+
+    Referee: the same trajectory in float64 (`_adam_noise_bands`).  EVERY element of every tensor must lie within
+    K = 8 times the spread that fp32-grade gradient noise induces on that element, plus four fp32 ulps per optimizer step of the
+    largest number the update handles (the weight before, after, or the step lr itself: Adam's moments, square root, quotient
+    and `p -= ...` each round once in fp32, in the reference as on the device);
+    K was fixed before the first run.  The fp32 oracle trajectory -- the
+    reference's own arithmetic -- is held to the same band, so a band it cannot meet itself would show.  (Round 2 widened a
+    fixed band around the fp32 oracle after a red run; a first float64 version of this test compared largest errors per
+    tensor and failed on luck: 7e-8 against 1.5e-8 on one element of var_layers.3.weight whose gradient sits near Adam's eps,
+    while every gradient tensor of the device is 0.2-1.3x as far from float64 as torch's, tools/diag_grad_err.py.)"""
     import pinn_amd
     from pinn_amd import synth
+    K = 8.0
     N, H, epochs, seed = 600, 128, 2, 77
     ds = synth.make_dataset(N, (), seed=9)
     torch.manual_seed(3)
@@ -265,22 +310,19 @@ def test_train_dnn_philox_masks_vs_oracle(batch_size):
     sd = m.dnn.state_dict()
     P = [sd[n].detach().cpu().clone() for n in names]
     m.train_dnn(epochs, batch_size=batch_size)
-    opt = O.AdamState(P)
-    step = 0
     bounds = [(0, N)] if batch_size is None else [(s, min(N, s + batch_size)) for s in range(0, N, batch_size)]
-    for epoch in range(epochs):
-        for s, e in bounds:
-            step += 1
-            masks = O.philox_masks_for_net(seed, step, s, e - s, H, 3, [0.2] * 4)
-            _, _, g, _, _ = O.nll_loss_and_grads(P, ds[0][s:e], ds[1][s:e], [0.2] * 4, masks)
-            opt.step(P, g, 0.01)
+    mask_fn = lambda step, s, e: (O.philox_masks_for_net(seed, step, s, e - s, H, 3, [0.2] * 4), [0.2] * 4)
+    w64, w32, spread = _adam_noise_bands(P, ds[0], ds[1], bounds, epochs, mask_fn, 0.01)
     got = m.dnn.state_dict()
-    for n, p in zip(names, P):
-        a, b = got[n].cpu().numpy(), p.detach().numpy()
-        err, tol = np.abs(a - b), 5e-6 + 5e-4 * np.abs(b)
-        # Adam divides by sqrt(v): an element whose gradient is ~0 turns fp32 summation-order noise into a visible step, so
-        # one element in ten thousand may sit just outside the band (never by more than a fraction of lr = 0.01 per step)
-        assert (err > tol).mean() <= 1e-4 and err.max() <= 1e-4, (n, int((err > tol).sum()), float(err.max()))
+    n_steps = epochs * len(bounds)
+    for n, p0, r64, r32, sp in zip(names, P, w64, w32, spread):
+        dev = got[n].cpu().double().numpy()
+        big = np.maximum(np.maximum(np.abs(p0.numpy()), np.abs(r64)), 0.01).astype(np.float32)
+        band = K * sp + 4 * n_steps * np.spacing(big).astype(np.float64)
+        worst = lambda v: float((np.abs(v - r64) / band).max())
+        assert worst(r32) <= 1.0, ("the fp32 oracle leaves its own band", n, worst(r32))
+        assert worst(dev) <= 1.0, (n, worst(dev), worst(r32))
+        assert np.abs(dev - r32).max() <= 2e-3, (n, float(np.abs(dev - r32).max()))      # sanity: the steps happened (lr = 0.01)
 
 
 def test_reference_main_flow(tmp_path):

@@ -328,12 +328,81 @@ def test_forward_wide_multi_chunk(lib):
         np.testing.assert_allclose(lv[lo:hi], lvf.numpy().reshape(-1), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("H,nh", [(256, 3), (512, 2)])
+def test_weight_outside_the_split_operand_range_is_reported(lib, H, nh):
+    """Scheme X3 stores fp16(64 w): one weight of 2000 in a hidden matrix is outside its domain, while the fp32 reference
+    (01:389-438) computes a finite output.  The kernels must not return wrong finite numbers quietly: the forward output of
+    every row is non-finite, pinn_net_range_status reports PINN_E_RANGE after the forward AND after a training call, the
+    record clears when the weight is back in range, and -- fused nets -- exact fp32 matches the oracle on the same weights."""
+    import hip_helpers as hh
+    from pinn_amd import _lib, synth
+    N = 300
+    P = O.init_params([8] + [H] * nh + [1], seed=5)
+    x = synth.make_dataset(N, (), seed=5)[0]
+    y = torch.zeros(N)
+    good = hh.flat_params(P, H, nh).to(hh.dev())
+    P_bad = [p.clone() for p in P]
+    P_bad[2][7, 11] = 2000.0                                   # layers.layer_1.weight
+    bad = hh.flat_params(P_bad, H, nh).to(hh.dev())
+    xd = x.to(hh.dev())
+    net = hh.make_net(lib, H, nh, 2)
+    status = lambda: lib.pinn_net_range_status(ctypes.byref(net), hh.stream())
+    u, lv = hh.forward(lib, H, nh, good, xd, precision=2)
+    assert status() == 0 and bool(torch.isfinite(u).all())
+    u, lv = hh.forward(lib, H, nh, bad, xd, precision=2)
+    assert status() == -4
+    assert not bool(torch.isfinite(u).any()), "a weight outside fp16(64 w) must not give finite outputs quietly"
+    g, _ = hh.train_grads(lib, H, nh, bad, xd, y.to(hh.dev()), None, precision=2)
+    assert status() == -4
+    g, _ = hh.train_grads(lib, H, nh, good, xd, y.to(hh.dev()), None, precision=2)
+    assert status() == 0 and bool(torch.isfinite(g).all())
+    with torch.no_grad():
+        uo, lvo = O.mlp_forward(P_bad, x)
+    assert bool(torch.isfinite(uo).all())
+    if H <= 256:
+        u32, lv32 = hh.forward(lib, H, nh, bad, xd, precision=0)
+        np.testing.assert_allclose(u32.cpu().numpy(), uo.numpy().reshape(-1), rtol=2e-5, atol=2e-5)
+        fp32net = hh.make_net(lib, H, nh, 0)
+        assert lib.pinn_net_range_status(ctypes.byref(fp32net), hh.stream()) == 0
+
+
+def test_model_check_range_raises():
+    """The Python surface turns PINN_E_RANGE into an exception where it synchronises anyway (predict, get_MC_samples,
+    train_dnn's log lines), and `set_precision("fp32")` is the way out the message names."""
+    import pinn_amd
+    from pinn_amd import _lib, synth
+    ds = synth.make_dataset(200, (), seed=1)
+    torch.manual_seed(0)
+    m = pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, 128, 128, 1], ds[4], ds[5], p=0.2, logvar=True)
+    m.verbose = False
+    m.predict(ds[0], ds[4])
+    with torch.no_grad():
+        m.dnn.state_dict()["layers.layer_1.weight"][3, 4] = -5000.0
+    with pytest.raises(_lib.PinnRangeError):
+        m.predict(ds[0], ds[4])
+    with pytest.raises(_lib.PinnRangeError):
+        pinn_amd.get_MC_samples(m, ds[2], ds[4], mc_times=2, dropout=0.4)
+    m.dnn.set_precision("fp32")
+    u, lv = m.predict(ds[0], ds[4])
+    assert np.all(np.isfinite(u)) and np.all(np.isfinite(lv))
+    m.dnn.set_precision("f32x6")
+    with pytest.raises(_lib.PinnRangeError):
+        m.train_dnn(1)              # (the step itself has run by the time the log line checks: the weights are NaN afterwards)
+
+
 @pytest.mark.parametrize("prec", [2, 3])
 def test_gradient_error_no_worse_than_torch_fp32(lib, prec):
     """How exact is "fp32-accurate"?  Every gradient tensor of [8,256,256,256,1] on 4096 rows against a float64 autograd of
-    the oracle, beside torch's own fp32 autograd (the reference's arithmetic) against the same: the device's rms error must
-    not exceed 3x torch's and its largest error 3x torch's largest (measured: 0.1-1.5x, and 2.4x for one bias vector -- 4096
-    fp32 additions in slice order against torch's pairwise sums, the same in both split schemes)."""
+    the oracle, beside torch's own fp32 autograd (the reference's arithmetic) against the same: for the default precision the
+    device's rms error must not exceed 2x torch's and its largest error 2x torch's largest, every tensor -- the factor the
+    test was written with (round 2 widened it to 3 after a red run; measured now: 0.04-1.5, tools/diag_grad_err.py).
+    The opt-in PINN_PREC_F32X6_G6 is held to 3x, for a reason that is the hardware's: its hidden-layer BIAS gradients sit at
+    2.3-2.4x, twice the default's, because it issues twice the MFMAs per product and a 16-bit MFMA does not round its 32
+    products into the accumulator as one sum -- products below the accumulator's last bits are cut off one by one
+    (tools/mfma_round_probe.hip: 32 products of 1.75 / 32 ulp each leave the accumulator unchanged, one product of 1.75 ulp
+    rounds it up by 2) -- a bias of constant sign that survives in a sum over rows with no weights in it; the exact-fp32
+    MFMA is an fmaf chain and shows 0.8-1.1x.  Slab reduction and bias sums accumulate in float64 in every family."""
+    K = 2.0 if prec == 2 else 3.0
     import hip_helpers as hh
     from pinn_amd import synth
     H, nh, N = 256, 3, 4096
@@ -351,8 +420,8 @@ def test_gradient_error_no_worse_than_torch_fp32(lib, prec):
             continue
         a, b, c = a.double().numpy().reshape(-1), b.double().numpy().reshape(-1), c.numpy().reshape(-1)
         rms = lambda e: float(np.sqrt((e ** 2).mean()))
-        assert rms(a - c) <= 3.0 * rms(b - c) + 1e-9 * rms(c), (n, rms(a - c) / rms(c), rms(b - c) / rms(c))
-        assert np.abs(a - c).max() <= 3.0 * np.abs(b - c).max() + 1e-8 * np.abs(c).max(), (n, np.abs(a - c).max(), np.abs(b - c).max())
+        assert rms(a - c) <= K * rms(b - c) + 1e-9 * rms(c), (n, rms(a - c) / rms(c), rms(b - c) / rms(c))
+        assert np.abs(a - c).max() <= K * np.abs(b - c).max() + 1e-8 * np.abs(c).max(), (n, np.abs(a - c).max(), np.abs(b - c).max())
 
 
 @pytest.mark.parametrize("prec", [2, 3])

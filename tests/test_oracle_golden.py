@@ -36,6 +36,21 @@ def test_philox_mask_statistics():
     assert not np.array_equal(O.philox_keep_mask(7, 10, 0, 64, 2, 128, 0.4), full[:64])
 
 
+def test_philox_mask_unbiased_under_reference_scale():
+    """01:405-406: torch's Dropout(p) keeps with probability exactly 1 - p and scales by 1 / (1 - p), so E[mask * scale] = 1.
+    The on-chip spec compares a 16-bit draw with round(65536 p): the realised keep probability times the reference's
+    scale must be 1 to 2^-17 / (1 - p) (the 8-bit draws of round 2 gave 1.00098 / 1.0026 at p = 0.2 / 0.4), the sample mean of
+    a large mask must agree with it within 4 standard errors, and a positive p must never round to "no dropout"."""
+    for p in (0.05, 0.2, 0.4, 0.6, 0.9):
+        thr = O.dropout_threshold16(p)
+        assert abs((1.0 - thr / 65536.0) / (1.0 - p) - 1.0) <= 2.0 ** -17 / (1.0 - p) * 1.0001       # 3.8e-6 at p = 0.2
+        m = O.philox_keep_mask(seed=21, stream=4, row0=1 << 20, n_rows=4096, layer_id=2, width=256, p=p)
+        se = np.sqrt(p * (1 - p) / m.size)
+        assert abs(m.mean() - (1 - p)) < 4 * se
+    assert O.dropout_threshold16(0.0) == 0 and O.dropout_threshold16(1e-7) == 1
+    assert not O.philox_keep_mask(1, 1, 0, 8, 0, 32, 1.0 - 1e-9).any()
+
+
 @pytest.mark.parametrize("fname,H", [("g_net128.npz", 128), ("g_net256.npz", 256)])
 def test_forward_eval_and_masked(fname, H):
     g = load_golden(fname)
