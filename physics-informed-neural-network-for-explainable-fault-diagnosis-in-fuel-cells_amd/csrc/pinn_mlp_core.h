@@ -490,8 +490,13 @@ struct TrainBuffers {
   float* slabs;
   long long t16;
   int n_slices;
-  unsigned* amax;     // PINN_PREC_F32X6 (fused nets): bits of max |d pre-activation| over the whole call (non-negative floats order like
-                      // unsigned integers: atomicMax, order-independent), the fp16 weight-gradient kernels' common scale
+  unsigned* amax;     // PINN_PREC_F32X6: bits of max |d pre-activation| over the whole call (non-negative floats order like unsigned
+                      // integers: atomicMax, order-independent): the wide nets' fp16 weight-gradient kernels' common scale; the range
+                      // record's gradient check (pinn_net_range_status)
+  // PINN_PREC_F32X6 on the fused nets (packed stash, pinn_x6_core.h):
+  unsigned* emax;     // bits of max over rows of max(|du|, |dz|): the forward kernel's atomicMax, zeroed by the pack kernel before it
+  void* rowmeta;      // [t16][256 B]: per tile the rows' scales t_r, the two fp16 parts of du_r * norm_r, dz_r (struct RowMeta)
+  int qboost;         // c of t_r = 2^(e_r - E + c): the headroom 8 |h| <= 8 / (1 - p) leaves in fp16
 };
 
 // kernel arguments of the forward / MC-dropout kernels (fp32 and bf16 variants)

@@ -274,11 +274,13 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
     for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
-  // (bias sums in float64: a slice adds up to a few thousand rows per lane one after the other, where torch sums pairwise)
+  // (bias sums: a slice adds up to a few thousand rows per lane one after the other, where torch sums pairwise -- fp32 over
+  //  eight tiles, those partial sums in float64; float64 adds in every tile cost the layer-0 kernel a quarter of its time)
   double bsum[TI];
-  float vq[TJ], vr[TI];
+  float bpart[TI], vq[TJ], vr[TI];
+  int n_part = 0;
 #pragma unroll
-  for (int ti = 0; ti < TI; ++ti) { bsum[ti] = 0.0; vr[ti] = 0.f; }
+  for (int ti = 0; ti < TI; ++ti) { bsum[ti] = 0.0; bpart[ti] = 0.f; vr[ti] = 0.f; }
 #pragma unroll
   for (int tj = 0; tj < TJ; ++tj) vq[tj] = 0.f;
 
@@ -324,7 +326,11 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-        for (int sg = 0; sg < 2; ++sg) bsum[ti] += (double)((cur.a[ti][sg][0] + cur.a[ti][sg][1]) + (cur.a[ti][sg][2] + cur.a[ti][sg][3]));
+        for (int sg = 0; sg < 2; ++sg) bpart[ti] += (cur.a[ti][sg][0] + cur.a[ti][sg][1]) + (cur.a[ti][sg][2] + cur.a[ti][sg][3]);
+      if ((++n_part & 7) == 0) {
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) { bsum[ti] += (double)bpart[ti]; bpart[ti] = 0.f; }
+      }
       if (a.dvr) {
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
@@ -389,7 +395,8 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
   if (wj == 0) {
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti) {
-      const float b = (float)(bsum[ti] + __shfl_xor(bsum[ti], 32, 64));
+      const double bl = bsum[ti] + (double)bpart[ti];
+      const float b = (float)(bl + __shfl_xor(bl, 32, 64));
       if (hh == 0) a.db[so + i0 + ti * 32 + i] = b;
       if (a.dvr) {
         const float v = vr[ti] + __shfl_xor(vr[ti], 32, 64);
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
 struct Workspace {
   long long t16;
   size_t off_stash_h, off_stash_v1, off_stash_v2, off_dpre_h, off_dpre_v1, off_dpre_v2, off_keep, off_du, off_dz, off_loss,
-      off_amax, off_slabs;
+      off_amax, off_rowmeta, off_slabs;
   int n_slices;
   size_t total;
 };
@@ -500,13 +507,24 @@ static Workspace plan_workspace(const pinn_net_t* net, long long n_rows) {
   w.off_du = take((size_t)w.t16 * 16 * 4);
   w.off_dz = take((size_t)w.t16 * 16 * 4);
   w.off_loss = take((size_t)1024 * kLossTerms * 8);
-  w.off_amax = take(256);
+  w.off_amax = take(256);                                   // [0] TrainBuffers::amax, [1] ::emax
+  w.off_rowmeta = take((size_t)w.t16 * 256);                // struct RowMeta records
   const long long t32 = (w.t16 + 1) / 2;
   w.n_slices = (int)(t32 < kMaxSlices ? (t32 < 1 ? 1 : t32) : kMaxSlices);
   ParamLayout L{(int)H, (int)nh};
   w.off_slabs = take((size_t)w.n_slices * L.total() * 4);
   w.total = o;
   return w;
+}
+
+// c of the packed weight gradients' row scale t_r = 2^(e_r - E + c) (pinn_x6_core.h): 8 |h| t_r must stay a finite fp16 with
+// |h| <= the largest dropout scale of the call
+static int row_scale_boost(const DropDev& d, int nh) {
+  float smax = 1.0f;
+  if (d.mode != PINN_DROP_NONE)
+    for (int l = 0; l <= nh; ++l) smax = d.scale[l] > smax ? d.scale[l] : smax;
+  int c = (int)floor(log2(65504.0 / (8.0 * (double)smax)));
+  return c < 0 ? 0 : (c > 12 ? 12 : c);
 }
 
 static int check_net_t(const pinn_net_t* net) {
@@ -566,6 +584,7 @@ int launch_train_chain_wide(const pinn_net_t* net, const float* d_params, const 
 int launch_train_bf16(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y, long long n_rows,
                       long long n_global, const DropDev& drop, const TrainBuffers& b, unsigned phases, int* grid_out, void* stream);
 int dispatch_wgrad_x6(const WgradArgs& a, int ns, void* stream);   // pinn_x6_wgrad.hip
+int dispatch_wgrad_p(const WgradPArgs& a, void* stream);            // pinn_x6_wgrad.hip: packed operands (PINN_PREC_F32X6, fused nets)
 }
 
 using namespace pinn;
@@ -652,6 +671,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
       b.keep = a.keep; b.du = a.du; b.dz = a.dz; b.loss_part = a.loss_part;
       b.slabs = (float*)(base + w.off_slabs); b.t16 = w.t16; b.n_slices = w.n_slices;
       b.amax = (unsigned*)(base + w.off_amax);
+      b.emax = b.amax + 1; b.rowmeta = base + w.off_rowmeta; b.qboost = row_scale_boost(a.drop, nh);
       rc = H > 256 ? launch_train_chain_wide(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, &grid, stream)
                    : launch_train_chain_x6(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, which, &grid, stream);
       if (rc) return rc;
@@ -687,6 +707,25 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     // every layer but the input one: split-bf16 products on the matrix cores for PINN_PREC_F32X6
     // operand split of the weight-gradient kernels: 0 = exact fp32 kernels; 3 = three bf16 parts, six products (x6); 4 = two fp16
     // parts under the common scale the X3 backward kernels measured (PINN_PREC_F32X6); 1 = bf16-mixed (wide nets)
+    if (net->precision == PINN_PREC_F32X6 && H <= 256) {
+      // packed stash: the chain kernels left every operand as fp16 fragments (pinn_x6_core.h), the row scales in the meta records
+      WgradPArgs p{};
+      p.meta = base + w.off_rowmeta; p.emax = (const unsigned*)(base + w.off_amax) + 1; p.qboost = row_scale_boost(a.drop, nh);
+      p.t16 = w.t16; p.n_slices = w.n_slices; p.slab_stride = tot;
+      const long long hb = hs * 4;      // bytes per hidden-layer stash
+      for (int l = 1; l < nh; ++l) {
+        p.P = (const char*)a.dpre_h + l * hb; p.Q = (const char*)a.stash_h + (l - 1) * hb; p.OUT = H; p.IN = H; p.dW = slabs + L.w(l); p.db = slabs + L.b(l);
+        if ((rc = dispatch_wgrad_p(p, stream))) return rc;
+      }
+      // variance head layer 0 (+ predict weight: dw_p[j] = sum du * h_last[j])
+      p.P = (const char*)a.dpre_v1; p.Q = (const char*)a.stash_h + (nh - 1) * hb; p.OUT = H / 2; p.IN = H; p.dW = slabs + L.wv0(); p.db = slabs + L.bv0();
+      p.dvq = slabs + L.wp();
+      if ((rc = dispatch_wgrad_p(p, stream))) return rc;
+      // variance head layer 1 (+ final weight: dwv2[i] = sum dz * v2[i], fp32 operands)
+      p.P = (const char*)a.dpre_v2; p.Q = (const char*)a.stash_v1; p.OUT = H / 4; p.IN = H / 2; p.dW = slabs + L.wv1(); p.db = slabs + L.bv1();
+      p.dvq = nullptr; p.s2 = a.dz; p.R = a.stash_v2; p.dvr = slabs + L.wv2();
+      if ((rc = dispatch_wgrad_p(p, stream))) return rc;
+    } else {
     const int ns = net->precision == PINN_PREC_F32X6 ? 4 : (net->precision == PINN_PREC_F32X6_G6 ? 3 : (net->precision == PINN_PREC_BF16 ? 1 : 0));
     auto wgrad = [&](const WgradArgs& wa) { return ns ? dispatch_wgrad_x6(wa, ns, stream) : dispatch_wgrad(wa, st); };
     for (int l = 1; l < nh; ++l) {
@@ -701,6 +740,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     g.P = a.dpre_v2; g.Q = a.stash_v1; g.OUT = H / 4; g.IN = H / 2; g.dW = slabs + L.wv1(); g.db = slabs + L.bv1();
     g.s1 = nullptr; g.dvq = nullptr; g.s2 = a.dz; g.R = a.stash_v2; g.dvr = slabs + L.wv2();
     if ((rc = wgrad(g))) return rc;
+    }
   }
 
   if (phases & PINN_PHASE_REDUCE) {

@@ -20,5 +20,20 @@ struct WgradArgs {
   const unsigned* amax;     // fp16 scheme only: bits of max |P| over the call (TrainBuffers::amax)
 };
 
+// the packed form (PINN_PREC_F32X6 on the fused nets): operands are the chain kernels' fp16 fragments, pinn_x6_core.h packed_ptr
+struct WgradPArgs {
+  const char* P;     // [T16][OUT / 32][2 KB]  d pre-activation in the rows' normalised units: parts hi, lo
+  const char* Q;     // [T16][IN / 32][2 KB]   8 x the input activation: parts hi, lo
+  const void* meta;  // [T16][256 B]: struct RowMeta records (row scales t_r, du_r norm_r as two fp16 parts, dz_r)
+  const unsigned* emax;   // bits of the call's largest max(|du|, |dz|) -> E
+  int qboost;             // c
+  int OUT, IN;
+  long long t16;
+  int n_slices;
+  long long slab_stride;
+  float* dW; float* db;
+  float* dvq;                                     // optional: dvq[j] = sum_rows du[row] Q[j][row]   (du from the meta records)
+  const float* s2; const float* R; float* dvr;    // optional: dvr[i] = sum_rows dz[row] R[i][row]   (R fp32 [T16][OUT][16]; dz from the meta records, s2 only says so)
+};
 
 }  // namespace pinn

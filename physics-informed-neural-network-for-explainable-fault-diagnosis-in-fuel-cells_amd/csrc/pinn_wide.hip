@@ -84,7 +84,8 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
     const long long t16 = tile * 8 + wave;
     const long long lrow = t16 * 16 + (lane & 15);
     const bool valid = lrow < a.n_rows;
-    const RowCtx c{lane, kq, a.row_base + lrow, lrow, a.n_rows, a.pass, a.drop.mode};
+    // (injected masks are indexed by the LOCAL row: padding rows of the last tile read the last real row's words, never past the buffer)
+    const RowCtx c{lane, kq, a.row_base + lrow, lrow < a.n_rows ? lrow : a.n_rows - 1, a.n_rows, a.pass, a.drop.mode};
     const float* in_tile = a.in + t16 * a.IN * 16;
     auto fetch = [&](int g) { ring.fetch(in_tile + 32 * g * 16, g & 1); };
     // scale of the B operand: activations x 8 (X3 forward); gradients x the row's normalisation 2^(4 - e), max(|du|, |dz|) =
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(256) void wide_input_kernel(InputArgs a) {
     const long long lrow = t16 * 16 + (lane & 15);
     const long long srow = lrow < a.n_rows ? lrow : a.n_rows - 1;
     const f32x4 xa = reinterpret_cast<const f32x4*>(a.x)[srow * 2], xb = reinterpret_cast<const f32x4*>(a.x)[srow * 2 + 1];
-    const RowCtx c{lane, kq, a.row_base + lrow, lrow, a.n_rows, a.pass, a.drop.mode};
+    // (injected masks are indexed by the LOCAL row: padding rows of the last tile read the last real row's words, never past the buffer)
+    const RowCtx c{lane, kq, a.row_base + lrow, lrow < a.n_rows ? lrow : a.n_rows - 1, a.n_rows, a.pass, a.drop.mode};
     float* out_tile = a.out + (t16 * a.H + 4 * kq) * 16 + (lane & 15);
     for (int fp = 0; fp < a.H / 32; ++fp) {
       f32x4 v[2];
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(256) void wide_loss_kernel(LossArgs a) {
 }  // namespace wide
 
 namespace x6 {
-void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st);   // pinn_x6.hip
+void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st, unsigned* zero_word = nullptr);   // pinn_x6.hip
 }
 
 // scratch behind the packed weights (floats): two activation buffers, v1, v2, the MC sums

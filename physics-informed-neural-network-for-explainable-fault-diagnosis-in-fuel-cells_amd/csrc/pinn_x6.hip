@@ -21,7 +21,8 @@ static int cu_count_x() { return cu_count_cached(); }
 // writes whether it met a weight outside that (or a non-finite one) into its own word of `status` -- plain stores, rewritten
 // by every call -- and workgroup (0, 0) clears the word of the gradient check that a training call's finalize kernel sets.
 __global__ __launch_bounds__(256) void pack_x6_kernel(const float* __restrict__ params, __bf16* __restrict__ packed, PackJobs6 jobs,
-                                                      unsigned* __restrict__ status) {
+                                                      unsigned* __restrict__ status, unsigned* __restrict__ zero_word) {
+  if (zero_word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_word = 0u;      // TrainBuffers::emax, for the forward kernel behind us
   const PackJob j = jobs.j[blockIdx.y];
   const long long n = (long long)j.rows * j.Kp;
   int bad = 0;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(const float* __restrict__ 
   }
 }
 
-void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st) {
+void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st, unsigned* zero_word) {
   const int H = net->hidden, nh = net->n_hidden;
   ParamLayout L{H, nh};
   PackLayout K{H, nh};
@@ -78,7 +79,7 @@ void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st
   jobs.copy_stride = K.total();
   jobs.with_f16 = 1;
   static_assert(kRangeStatusBytes >= (18 * kRangePackBlocks + 1) * sizeof(unsigned), "range record too small");
-  hipLaunchKernelGGL(pack_x6_kernel, dim3(kRangePackBlocks, n), dim3(256), 0, st, d_params, (__bf16*)net->d_packed, jobs, range_status_words(net));
+  hipLaunchKernelGGL(pack_x6_kernel, dim3(kRangePackBlocks, n), dim3(256), 0, st, d_params, (__bf16*)net->d_packed, jobs, range_status_words(net), zero_word);
 }
 
 // WAVES = 8: 128-row tiles, two waves per SIMD.  WAVES = 4 (small row counts, fewer tiles than CUs): 64-row tiles, one
@@ -162,7 +163,7 @@ int launch_forward_x6(const pinn_net_t* net, const FwdArgs& a, bool mc, void* st
   using namespace x6;
   hipStream_t st = (hipStream_t)stream;
   (void)hipGetLastError();
-  launch_pack_x6(net, a.params, st);
+  launch_pack_x6(net, a.params, st, nullptr);
   const int cus = cu_count_x();
   const long long t128 = (a.n_rows + 127) / 128;
 #ifdef PINN_DEBUG_HOOKS

@@ -465,8 +465,8 @@ __device__ __forceinline__ float tanh_pre(float x, float pre) {
 // kPack (PINN_PREC_F32X6 on the fused nets): the stash keeps the group as the B fragments just built -- the two fp16 parts of
 // S::kActScale x the activation, 16 B per lane and part -- instead of fp32 values: the backward chain rebuilds the activation
 // from hi + lo (22 bits, what the forward MFMAs used), and the weight-gradient kernel reads ready operands instead of
-// splitting 7.7 GB of fp32 again (round 2: 7.6 VALU instructions per MFMA there).  "Dropped" is still h == 0: a kept
-// activation below 2^-25 / 8 rounds to (0, 0) and is taken for dropped -- about two of the 1e9 activations of a 1e6-row step.
+// splitting 7.7 GB of fp32 again (round 2: 7.6 VALU instructions per MFMA there).  "Dropped" is still h == 0, so a kept
+// activation must never pack to (0, 0): see the kept-zero rule at the tanh below.
 template <typename S, bool kBits, bool kDot, int k, int FP, bool kPack = false>
 __device__ __forceinline__ void prep_micro(PrepBase& s, f32x4& v0, f32x4& v1, const DropDev& d, const RowCtx& c, const LayerDrop ld, float pre,
                                            int layer, const float* wp32, float& up, bool dot_on, typename S::Frag& out, float* sp = nullptr) {
@@ -491,8 +491,14 @@ __device__ __forceinline__ void prep_micro(PrepBase& s, f32x4& v0, f32x4& v1, co
     constexpr int r = k - 2;
     // scale * tanh(x) = scale - 2 scale / (e^{2x} + 1): the dropout / operand scale rides in the tanh's last fma
     const float m2s = -2.0f * ld.scale;
-    const float a0 = fmaf(m2s, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v0[r] * pre) + 1.0f), ld.scale);
-    const float a1 = fmaf(m2s, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v1[r] * pre) + 1.0f), ld.scale);
+    float a0 = fmaf(m2s, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v0[r] * pre) + 1.0f), ld.scale);
+    float a1 = fmaf(m2s, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v1[r] * pre) + 1.0f), ld.scale);
+    if constexpr (kPack) {
+      // the backward pass reads "dropped" off h == 0, and this tanh IS exactly 0 for |x| < ~3e-8 (exp2 rounds to 1: about 80
+      // kept activations of a 1e6-row step): a kept zero becomes the smallest fp16 subnormal, 2^-24 / kActScale in h
+      a0 = a0 == 0.0f ? 0x1p-24f : a0;
+      a1 = a1 == 0.0f ? 0x1p-24f : a1;
+    }
     const bool k0 = kBits ? ((s.keep >> r) & 1u) != 0 : keep_draw<0, r>(s, ld.thr);
     const bool k1 = kBits ? ((s.keep >> (4 + r)) & 1u) != 0 : keep_draw<1, r>(s, ld.thr);
     const float hs0 = k0 ? a0 : 0.0f;                      // the matrix operand: S::kActScale x the activation
@@ -758,7 +764,34 @@ struct StashRing {
   __device__ __forceinline__ float read(int buf, int b, int r) const {
     return *reinterpret_cast<const float*>(lds + buf * 2048 + ((16 * b + 4 * (lane >> 4) + r) * 16 + (lane & 15)) * 4);
   }
+  // packed block: this lane's fragment of part `part` (0 = hi, 1 = lo)
+  __device__ __forceinline__ u32x4 read_frag(int buf, int part) const {
+    return *reinterpret_cast<const u32x4*>(lds + buf * 2048 + part * 1024 + (lane & 15) * 64 + (lane >> 4) * 16);
+  }
 };
+
+// the two fp16 parts of a packed stash group, as this lane holds them (dword r = (block 0, block 1) of register r)
+struct StashFrag {
+  u32x4 hi, lo;
+};
+// S::kActScale x the activation of block b, register r: hi + lo (exact in fp32)
+template <int B, int R>
+__device__ __forceinline__ float unpack_act(const StashFrag& f) {
+  const unsigned hw = f.hi[R], lw = f.lo[R];      // (scalars first: __builtin_bit_cast of a vector element reads element 0, hipcc 7.2)
+  const f16x2 h = __builtin_bit_cast(f16x2, hw), l = __builtin_bit_cast(f16x2, lw);
+  return (float)h[B] + (float)l[B];
+}
+
+// Row scale of the packed weight gradients.  The packed d pre-activations are the backward chain's operands: the row's
+// gradients times norm_r = 2^(4 - e_r), e_r the exponent of max(|du|, |dz|).  dW = sum_r d pre_r (x) h_r needs the true ones,
+// so the weight-gradient kernel multiplies the OTHER operand's row by t_r = 2^(e_r - E + c) (one v_pk_mul_f16 per dword),
+// E = the call's largest e_r (from TrainBuffers::emax, measured by the forward kernel), c = the headroom 8 |h| leaves in
+// fp16; the sums come out times 2^(4 - E + c).  Rows without gradient (all-zero or padding) take e_r = E.
+__device__ __forceinline__ int grad_exponent(float mx, int e_if_zero) {
+  int e = 0;
+  (void)frexpf(mx, &e);
+  return (mx > 0.0f && mx < __builtin_inff()) ? (e < -120 ? -120 : e) : e_if_zero;
+}
 
 // micro-step k of a backward group: raw d0, d1 = (acc_scale x) d loss / d h (two 16-feature blocks) -> d pre-activation in place,
 // split for the next matrix (k = 2 .. 5) and stashed for the weight-gradient kernels (dsp; k = 6).  h = post-dropout activation from
@@ -767,21 +800,32 @@ struct StashRing {
 // its normalisation (scheme X3, see backward_pass); the stash gets them back in true units: x unnorm.
 template <typename S, int k>
 __device__ __forceinline__ void bprep_micro(typename S::Frag& out, f32x4& d0, f32x4& d1, const StashRing& ring, int buf, float* dsp, float gscale,
-                                            float inv_scale, float unnorm, float& mx) {
-  if constexpr (k >= 2 && k < 6) {
+                                            float inv_scale, float unnorm, float& mx, StashFrag& sf) {
+  constexpr bool kPack = S::kCopies == 2;       // scheme X3 (PINN_PREC_F32X6): packed stash, see prep_micro
+  if constexpr (k == 1) {
+    if constexpr (kPack) { sf.hi = ring.read_frag(buf, 0); sf.lo = ring.read_frag(buf, 1); }
+  } else if constexpr (k >= 2 && k < 6) {
     constexpr int r = k - 2;
-    const float h0 = ring.read(buf, 0, r), h1 = ring.read(buf, 1, r);
+    // packed: inv_scale = 1 / (dropout scale x S::kActScale), the stash holds kActScale x h
+    const float h0 = kPack ? unpack_act<0, r>(sf) : ring.read(buf, 0, r), h1 = kPack ? unpack_act<1, r>(sf) : ring.read(buf, 1, r);
     const float a0 = h0 * inv_scale, a1 = h1 * inv_scale;
     const float g0 = d0[r] * (gscale * (1.0f - a0 * a0)), g1 = d1[r] * (gscale * (1.0f - a1 * a1));
     const float p0 = h0 != 0.0f ? g0 : 0.0f, p1 = h1 != 0.0f ? g1 : 0.0f;
     d0[r] = p0; d1[r] = p1;
     S::template split<r>(p0, p1, out);
-  } else if constexpr (k == 6) {      // the group's eight stores, behind the step's last DMA (PipeT::advance<8>)
+  } else if constexpr (k == 6) {      // the group's stores, behind the step's last DMA (PipeT::advance<kYoung>)
+    if constexpr (kPack) {            // the operands just built, in the row's normalised units (the weight-gradient kernel scales by row)
+      PINN_STASH_ST(reinterpret_cast<u32x4*>(dsp), out.hi);
+      PINN_STASH_ST(reinterpret_cast<u32x4*>(dsp + 256), out.lo);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      PINN_STASH_ST(dsp + r * 16, S::kActScale != 1.0f ? d0[r] * unnorm : d0[r]);
-      PINN_STASH_ST(dsp + (16 + r) * 16, S::kActScale != 1.0f ? d1[r] * unnorm : d1[r]);
-      if constexpr (S::kActScale != 1.0f) mx = fmaxf(fmaxf(mx, fabsf(d0[r])), fabsf(d1[r]));      // (normalised units; v_max3_f32)
+      for (int r = 0; r < 4; ++r) mx = fmaxf(fmaxf(mx, fabsf(d0[r])), fabsf(d1[r]));      // (normalised units; v_max3_f32)
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        PINN_STASH_ST(dsp + r * 16, S::kActScale != 1.0f ? d0[r] * unnorm : d0[r]);
+        PINN_STASH_ST(dsp + (16 + r) * 16, S::kActScale != 1.0f ? d1[r] * unnorm : d1[r]);
+        if constexpr (S::kActScale != 1.0f) mx = fmaxf(fmaxf(mx, fabsf(d0[r])), fabsf(d1[r]));
+      }
     }
   }
 }
@@ -793,12 +837,23 @@ __device__ __forceinline__ void bprep_micro(typename S::Frag& out, f32x4& d0, f3
 // row is one COLUMN of every product W^T d, so it may carry its own scale: each row's (du, dz) is normalised by an exact
 // power of two to max(|du|, |dz|) in [8, 16) (`norm`), the whole chain of that row runs on normalised values (bounded by
 // the weights' row sums, far inside fp16's range), and what goes to the stash is multiplied by 1 / norm again (exact).
+// What the packed weight-gradient kernels need besides the stash (scheme X3 only): E and the headroom c of the row scale
+// t_r (grad_exponent above), and this tile's 256-B record: fp16 [0..15] t_r, [16..31] / [32..47] the two fp16 parts of
+// du_r * norm_r (the predict head's weight gradient is a dot product with h like any other row of d pre); fp32 [32..47]
+// (bytes 128 ..) dz_r for the variance head's last weight, whose other operand stays fp32.
+struct RowMeta {
+  _Float16* rec;      // this tile's record (128 x f16), or nullptr
+  int E, c;
+};
 template <typename S, int H, int WAVES = 8>
 __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLayout& L, typename S::Pipe& pipe, const DropDev& d, int mode,
-                                              const StashX& sx, const StashRing& ring, int lane, float du, float dz, float& amax) {
+                                              const StashX& sx, const StashRing& ring, int lane, float du, float dz, float& amax,
+                                              const RowMeta meta = RowMeta{nullptr, 4, 0}) {
   constexpr int NT = H / 16, NT2 = H / 32, NT4 = H / 64, NP = H / 32, NC = S::kCopies;
   constexpr int NG1 = (H / 4) / 32 > 0 ? (H / 4) / 32 : 1;                 // K-groups of Wv1^T (K = H/4)
   constexpr int KPW = clog2(H), KPT0 = clog2((H / 2 + 63) & ~63), KPT1 = clog2((H / 4 + 63) & ~63);
+  constexpr bool kPack = NC == 2;                                          // scheme X3: packed stash (prep_micro)
+  constexpr int kSt = kPack ? 2 : 8;                                       // stash stores per prepared group
   using Frag = typename S::Frag;
   const int kq = lane >> 4;
   const SmallLayout SL{L.H, L.nh};
@@ -820,25 +875,35 @@ __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLa
   float unnorm = 1.0f;
   float mx = 0.0f;        // X3: max |d pre-activation| this lane stashes for this tile, in the row's normalised units
   if constexpr (S::kActScale != 1.0f) {
-    int e = 0;
-    const float mx = fmaxf(fabsf(du), fabsf(dz));
-    (void)frexpf(mx, &e);
-    e = mx > 0.0f ? (e < -120 ? -120 : e) : 4;                             // (all-zero row, padding: norm = 1)
+    const int e = grad_exponent(fmaxf(fabsf(du), fabsf(dz)), kPack ? meta.E : 4);      // (all-zero row, padding: no gradient to scale)
     const float norm = ldexpf(1.0f, 4 - e);
     unnorm = ldexpf(1.0f, e - 4);
+    if constexpr (kPack) {
+      if (meta.rec && lane < 16) reinterpret_cast<float*>(meta.rec)[32 + lane] = dz;
+    }
     du *= norm; dz *= norm;
+    if constexpr (kPack) {
+      if (meta.rec && lane < 16) {
+        const _Float16 dh16 = (_Float16)du;
+        meta.rec[lane] = (_Float16)ldexpf(1.0f, e - meta.E + meta.c);      // t_r <= 2^c; a power of two down to 2^-24, 0 below
+        meta.rec[16 + lane] = dh16;
+        meta.rec[32 + lane] = (_Float16)(du - (float)dh16);
+      }
+    }
   }
   constexpr float kInvW = 1.0f / (S::kAccScale / S::kActScale);            // 1 / weight scale: accumulators carry kWScale x W^T d
+  constexpr float kInvA = kPack ? 1.0f / S::kActScale : 1.0f;              // the packed stash holds kActScale x h
 
   PrepT<S> st;
+  StashFrag sf;
   constexpr int P1 = NG1 & 1;      // fragment buffer parity after Wv1^T (its group count is odd for H = 128)
   // ---- d pre_v2 = wv2 * dz * (1 - v2^2): the B operand of Wv1^T, all in registers
   f32x4 v2[NT4];
+  float* dsp2 = kPack ? packed_ptr(sx.dv2, sx.t16, H / 4, lane) : tiled_ptr(sx.dv2, sx.t16, H / 4, lane);
   {
     const float* vp = tiled_ptr(sx.v2, sx.t16, H / 4, lane);
 #pragma unroll
     for (int t = 0; t < NT4; ++t) load_block(vp, t, v2[t]);
-    float* sp = tiled_ptr(sx.dv2, sx.t16, H / 4, lane);
 #pragma unroll
     for (int t = 0; t < NT4; ++t) {
       const f32x4 w = *reinterpret_cast<const f32x4*>(smallp + SL.wv2() + t * 16 + 4 * kq);
@@ -849,27 +914,37 @@ __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLa
         true_units[r] = v2[t][r] * unnorm;
         if constexpr (S::kActScale != 1.0f) mx = fmaxf(mx, fabsf(v2[t][r]));
       }
-      store_block(sp, t, true_units);
+      if constexpr (!kPack) store_block(dsp2, t, true_units);
     }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const f32x4& second = NT4 >= 2 ? v2[NT4 >= 2 ? 1 : 0] : zero;           // H = 128: K = 32 of a padded 64, one real block
     static_for<4>([&](auto rc) { constexpr int r = decltype(rc)::value; S::template split<r>(v2[0][r], second[r], st.buf[0]); });
+    if constexpr (kPack) {      // group 0 of d pre_v2, packed (further groups: with their split, below)
+      PINN_STASH_ST(reinterpret_cast<u32x4*>(dsp2), st.buf[0].hi);
+      PINN_STASH_ST(reinterpret_cast<u32x4*>(dsp2 + 256), st.buf[0].lo);
+    }
   }
   const Mat m_t1{(unsigned)K.wv1t(), clog2(H / 32)}, m_t0{(unsigned)K.wv0t(), clog2(H / 16)};
   const Mat m_again{m_t1.off, m_t1.nrb_log, KPT1};                          // the next tile's first matrix (run-time row stride)
+  auto dv1_ptr = [&]() -> float* { return kPack ? packed_ptr(sx.dv1, sx.t16, H / 2, lane) : tiled_ptr(sx.dv1, sx.t16, H / 2, lane); };
+  auto dact_ptr = [&](int layer) -> float* { return kPack ? sx.dactp(layer, H, lane) : sx.dact(layer, H, lane); };
 
   // ---- d h_v1 = Wv1^T d pre_v2; lazily -> d pre_v1 (stash block i = its group)
   f32x4 dpv1[NT2];
   zero_blocks<NT2>(dpv1);
   {
     const LayerDrop ldv = layer_drop(d, mode, nh);
-    const float gscale = ldv.scale * kInvW, inv_scale = 1.0f / ldv.scale;
-    float* dsp = tiled_ptr(sx.dv1, sx.t16, H / 2, lane);
-    layer_x6<S, 0, NG1, NT2, KPT1, KPT0, NC * H / 32, NC * H / 16, true, WAVES, 0, 8, (WAVES <= H / 32 ? clog2(H / 32) : -1)>(
+    const float gscale = ldv.scale * kInvW, inv_scale = kInvA / ldv.scale;
+    float* dsp = dv1_ptr();
+    layer_x6<S, 0, NG1, NT2, KPT1, KPT0, NC * H / 32, NC * H / 16, true, WAVES, (kPack ? 2 : 0), kSt, (WAVES <= H / 32 ? clog2(H / 32) : -1)>(
         dpv1, pipe, m_t1, m_t0, lane, st,
         [&](auto gc, auto kc, Frag& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
           if constexpr (k >= 2 && k < 6 && 2 * g + 1 < NT4) S::template split<k - 2>(v2[2 * g][k - 2], v2[2 * g + 1][k - 2], out);
+          if constexpr (kPack && k == 6 && 2 * g + 1 < NT4) {
+            PINN_STASH_ST(reinterpret_cast<u32x4*>(dsp2 + 512 * g), out.hi);
+            PINN_STASH_ST(reinterpret_cast<u32x4*>(dsp2 + 512 * g + 256), out.lo);
+          }
         },
         [&](auto kc, Frag& out) {
           constexpr int k = decltype(kc)::value;
@@ -877,7 +952,7 @@ __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLa
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // block 0 was requested at the top of this pass
             fetch_block(1);
           }
-          bprep_micro<S, k>(out, dpv1[0], dpv1[1], ring, 0, dsp, gscale, inv_scale, unnorm, mx);
+          bprep_micro<S, k>(out, dpv1[0], dpv1[1], ring, 0, dsp, gscale, inv_scale, unnorm, mx, sf);
         });
   }
 
@@ -890,22 +965,22 @@ __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLa
   }
   {
     const LayerDrop ldv = layer_drop(d, mode, nh), ldh = layer_drop(d, mode, nh - 1);
-    const float gscale = ldv.scale * kInvW, inv_scale = 1.0f / ldv.scale, gscale_o = ldh.scale * kInvW, inv_scale_o = 1.0f / ldh.scale;
-    float* dsp = tiled_ptr(sx.dv1, sx.t16, H / 2, lane);
-    float* dsp_o = sx.dact(nh - 1, H, lane);
+    const float gscale = ldv.scale * kInvW, inv_scale = kInvA / ldv.scale, gscale_o = ldh.scale * kInvW, inv_scale_o = kInvA / ldh.scale;
+    float* dsp = dv1_ptr();
+    float* dsp_o = dact_ptr(nh - 1);
     const Mat next = nh > 1 ? Mat{(unsigned)K.wt(nh - 1), clog2(H / 16), KPW} : m_again;
-    layer_x6<S, P1, NP / 2, NT, KPT0, -1, NC * H / 16, NC * H / 16, true, WAVES, 8, 8, clog2(H / 16)>(
+    layer_x6<S, P1, NP / 2, NT, KPT0, -1, NC * H / 16, NC * H / 16, true, WAVES, kSt, kSt, clog2(H / 16)>(
         dh, pipe, m_t0, next, lane, st,
         [&](auto gc, auto kc, Frag& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
           if constexpr (k == 0) fetch_block(g + 1);
-          bprep_micro<S, k>(out, dpv1[2 * g], dpv1[2 * g + 1], ring, g & 1, dsp + 32 * g * 16, gscale, inv_scale, unnorm, mx);
+          bprep_micro<S, k>(out, dpv1[2 * g], dpv1[2 * g + 1], ring, g & 1, dsp + 32 * g * 16, gscale, inv_scale, unnorm, mx, sf);
         },
         [&](auto kc, Frag& out) {
           constexpr int k = decltype(kc)::value;
           if (nh > 1) {
             if constexpr (k == 0) fetch_block(NP / 2 + 1);
-            bprep_micro<S, k>(out, dh[0], dh[1], ring, (NP / 2) & 1, dsp_o, gscale_o, inv_scale_o, unnorm, mx);
+            bprep_micro<S, k>(out, dh[0], dh[1], ring, (NP / 2) & 1, dsp_o, gscale_o, inv_scale_o, unnorm, mx, sf);
           }
         },
         nh > 1);
@@ -917,23 +992,23 @@ __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLa
     f32x4 acc[NT];
     zero_blocks<NT>(acc);
     const LayerDrop ld_in = layer_drop(d, mode, l), ld_out = layer_drop(d, mode, l - 1);
-    const float gscale = ld_in.scale * kInvW, inv_scale = 1.0f / ld_in.scale, gscale_o = ld_out.scale * kInvW, inv_scale_o = 1.0f / ld_out.scale;
-    float* dsp = sx.dact(l, H, lane);
-    float* dsp_o = sx.dact(l - 1, H, lane);
+    const float gscale = ld_in.scale * kInvW, inv_scale = kInvA / ld_in.scale, gscale_o = ld_out.scale * kInvW, inv_scale_o = kInvA / ld_out.scale;
+    float* dsp = dact_ptr(l);
+    float* dsp_o = dact_ptr(l - 1);
     const int base = NP / 2 + (nh - 1 - l) * NP;           // stash block index of this layer's group 0
     const Mat mine{(unsigned)K.wt(l), clog2(H / 16)}, next = l > 1 ? Mat{(unsigned)K.wt(l - 1), clog2(H / 16), KPW} : m_again;
-    layer_x6<S, P1, NP, NT, KPW, -1, NC * H / 16, NC * H / 16, true, WAVES, 8, 8, clog2(H / 16)>(
+    layer_x6<S, P1, NP, NT, KPW, -1, NC * H / 16, NC * H / 16, true, WAVES, kSt, kSt, clog2(H / 16)>(
         acc, pipe, mine, next, lane, st,
         [&](auto gc, auto kc, Frag& out) {
           constexpr int g = decltype(gc)::value, k = decltype(kc)::value;
           if constexpr (k == 0) fetch_block(base + g + 1);
-          bprep_micro<S, k>(out, dh[2 * g], dh[2 * g + 1], ring, (base + g) & 1, dsp + 32 * g * 16, gscale, inv_scale, unnorm, mx);
+          bprep_micro<S, k>(out, dh[2 * g], dh[2 * g + 1], ring, (base + g) & 1, dsp + 32 * g * 16, gscale, inv_scale, unnorm, mx, sf);
         },
         [&](auto kc, Frag& out) {
           constexpr int k = decltype(kc)::value;
           if (l > 1) {
             if constexpr (k == 0) fetch_block(base + NP + 1);
-            bprep_micro<S, k>(out, acc[0], acc[1], ring, (base + NP) & 1, dsp_o, gscale_o, inv_scale_o, unnorm, mx);
+            bprep_micro<S, k>(out, acc[0], acc[1], ring, (base + NP) & 1, dsp_o, gscale_o, inv_scale_o, unnorm, mx, sf);
           }
         },
         l > 1);
@@ -941,25 +1016,48 @@ __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLa
     for (int t = 0; t < NT; ++t) dh[t] = acc[t];
   }
 
-  // ---- layer 0: d pre_0 = d h_0 * tanh' (no matrix follows: plain loads, all issued before the arithmetic)
+  // ---- layer 0: d pre_0 = d h_0 * tanh' (no matrix follows: plain loads, all issued before the arithmetic); fp32, true
+  //      units in every scheme: its weight gradient (K = 8 inputs) is the exact-fp32 kernel's
   {
     const LayerDrop ld0 = layer_drop(d, mode, 0);
-    const float gscale = ld0.scale * kInvW * unnorm, inv_scale = 1.0f / ld0.scale;       // straight to true units
-    const float* hp = sx.act(0, H, lane);
+    const float gscale = ld0.scale * kInvW * unnorm, inv_scale = kInvA / ld0.scale;       // straight to true units
     float* dsp = sx.dact(0, H, lane);
-    f32x4 hl[NT];
+    auto one = [&](float h, float dv) -> float {
+      const float a0 = h * inv_scale;
+      const float g0 = dv * (gscale * (1.0f - a0 * a0));
+      const float o = h != 0.0f ? g0 : 0.0f;
+      if constexpr (S::kActScale != 1.0f) amax = fmaxf(amax, fabsf(o));      // (already in true units)
+      return o;
+    };
+    if constexpr (kPack) {
+      const float* hp = sx.actp(0, H, lane);
+      StashFrag fr[NP];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) load_block(hp, t, hl[t]);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float a0 = hl[t][r] * inv_scale;
-        const float g0 = dh[t][r] * (gscale * (1.0f - a0 * a0));
-        dh[t][r] = hl[t][r] != 0.0f ? g0 : 0.0f;
-        if constexpr (S::kActScale != 1.0f) amax = fmaxf(amax, fabsf(dh[t][r]));      // (already in true units)
+      for (int g = 0; g < NP; ++g) {
+        fr[g].hi = *reinterpret_cast<const u32x4*>(hp + 512 * g);
+        fr[g].lo = *reinterpret_cast<const u32x4*>(hp + 512 * g + 256);
       }
-      store_block(dsp, t, dh[t]);
+      static_for<NP>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        static_for<4>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          dh[2 * g][r] = one(unpack_act<0, r>(fr[g]), dh[2 * g][r]);
+          dh[2 * g + 1][r] = one(unpack_act<1, r>(fr[g]), dh[2 * g + 1][r]);
+        });
+        store_block(dsp, 2 * g, dh[2 * g]);
+        store_block(dsp, 2 * g + 1, dh[2 * g + 1]);
+      });
+    } else {
+      const float* hp = sx.act(0, H, lane);
+      f32x4 hl[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) load_block(hp, t, hl[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[t][r] = one(hl[t][r], dh[t][r]);
+        store_block(dsp, t, dh[t]);
+      }
     }
   }
   if constexpr (S::kActScale != 1.0f) amax = fmaxf(amax, mx * unnorm);

@@ -1,8 +1,9 @@
 // pinn_x6_train.hip -- train_dnn's forward + aleatoric_loss + backward chain (01:949-953) with fp32-accurate
-// matrix products on the matrix cores (pinn_net_t.precision = PINN_PREC_F32X6; see pinn_x6_core.h): forward in
-// scheme X3 (two fp16 parts), backward in x6 (three bf16 parts).
-// Same stash layout and outputs as train_chain_kernel (pinn_train.hip): the weight-gradient and finalize
-// kernels that follow are shared.
+// matrix products on the matrix cores (pinn_x6_core.h).  PINN_PREC_F32X6: forward and backward in scheme X3 (two fp16
+// parts, three MFMAs per product), activations and d pre-activations stashed PACKED -- as the fp16 fragments the chain's
+// own MFMAs read -- for the backward kernel and the packed weight-gradient kernels (pinn_x6_wgrad.hip).
+// PINN_PREC_F32X6_G6: forward X3, backward x6 (three bf16 parts, six MFMAs), fp32 stash in train_chain_kernel's layout
+// (pinn_train.hip) and the split-in-registers weight-gradient kernels.  The finalize kernel is shared by all.
 #include <cstdlib>
 #include "pinn_x6_core.h"
 
@@ -27,7 +28,7 @@ struct TrainArgsX {
 // nothing in registers: du, dz go through their [rows] buffers (the weight-gradient kernels read them anyway), the
 // tanh'ed last variance blocks through the stash.
 // WAVES: 8 = 128-row tiles, two waves per SIMD; 4 = 64-row tiles, one wave per SIMD (small row counts, see mlp_x6_kernel)
-template <int H, bool kBits, int WAVES>
+template <int H, bool kBits, int WAVES, bool kPack>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_fwd_x3_kernel(TrainArgsX a, const __bf16* packed) {
   using S = X3;
   constexpr int kThreadsX = WAVES * 64, kTileRowsX = WAVES * 16;
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_fwd_x3_kernel(Tra
   const int lane = threadIdx.x & 63, wave = pipe.wave, kq = lane >> 4;
   const float inv_n = (float)(1.0 / (double)a.n_global);
   float s_nll = 0.f, s_abs = 0.f, s_mse = 0.f, s_du = 0.f, s_dz = 0.f;
+  float gmax = 0.f;        // kPack: max over this lane's rows of max(|du|, |dz|) -> TrainBuffers::emax (the row scales' reference)
   if (blockIdx.x == 0 && threadIdx.x == 0) *a.b.amax = 0u;      // the backward kernel (next in the stream) takes its atomicMax from 0
 
   const long long n_tiles = (a.n_rows + 127) / 128 * (128 / kTileRowsX);      // whole 128-row stash tiles
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_fwd_x3_kernel(Tra
 
     // ------------------------------------------------------------------ forward (activations stashed)
     float u, z;
-    forward_pass<S, H, kBits, true, WAVES>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z, &sx);
+    forward_pass<S, H, kBits, true, WAVES, kPack>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z, &sx);
 
     // ------------------------------------------------------------------ aleatoric_loss (01:916-927) and its gradient
     float du = 0.f, dz = 0.f;
@@ -92,7 +94,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_fwd_x3_kernel(Tra
         }
       }
       if (lane < 16) { a.b.du[t16 * 16 + lane] = du; a.b.dz[t16 * 16 + lane] = dz; }
+      gmax = fmaxf(gmax, fmaxf(fabsf(du), fabsf(dz)));          // (fmaxf drops a NaN: it reaches the gradients through du, dz themselves)
     }
+  }
+  if constexpr (kPack) {      // one atomicMax per wave on the float's bits: order-independent, so bitwise reproducible
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
+    if (lane == 0) atomicMax(a.b.emax, __float_as_uint(gmax));
   }
 
   // ---------------------------------------------------------------------- loss partial sums of this workgroup
@@ -142,12 +150,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_bwd_kernel(TrainA
   const StashRing ring{ring_lds + wave * 4096, lane};
   const long long n_tiles = (a.n_rows + 127) / 128 * (128 / kTileRowsX);
   float amax = 0.0f;       // X3: max |d pre-activation| this lane has stashed (true units)
+  // X3 (packed stash): the call's largest row exponent E, complete since the forward kernel ended (grad_exponent: 4 if no row has a gradient)
+  int E = 4;
+  if constexpr (S::kCopies == 2) E = grad_exponent(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(*a.b.emax)), 4);
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long t16 = tile * WAVES + wave;
     const StashX sx{(float*)a.b.stash_h, (float*)a.b.stash_v1, (float*)a.b.stash_v2, (float*)a.b.dpre_h, (float*)a.b.dpre_v1, (float*)a.b.dpre_v2,
                     a.b.t16, t16};
     const float du = a.b.du[t16 * 16 + (lane & 15)], dz = a.b.dz[t16 * 16 + (lane & 15)];
-    backward_pass<S, H, WAVES>(small, L, pipe, a.drop, a.drop.mode, sx, ring, lane, du, dz, amax);
+    const RowMeta meta{S::kCopies == 2 ? (_Float16*)a.b.rowmeta + t16 * 128 : nullptr, E, a.b.qboost};
+    backward_pass<S, H, WAVES>(small, L, pipe, a.drop, a.drop.mode, sx, ring, lane, du, dz, amax, meta);
   }
   if constexpr (S::kActScale != 1.0f) {
     // the call's common scale for the fp16 weight-gradient kernels: one atomicMax per wave on the float's bits (non-negative
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_bwd_kernel(TrainA
   }
 }
 
-void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st);   // pinn_x6.hip
+void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st, unsigned* zero_word = nullptr);   // pinn_x6.hip
 
 }  // namespace x6
 
@@ -168,7 +180,9 @@ int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const fl
                           long long n_global, const DropDev& drop, const TrainBuffers& b, unsigned which, int* grid_out, void* stream) {
   using namespace x6;
   hipStream_t st = (hipStream_t)stream;
-  launch_pack_x6(net, d_params, st);
+  const bool fast_bwd = net->precision == PINN_PREC_F32X6;           // backward chain in scheme X3 + packed stash (PINN_PREC_F32X6_G6: x6, fp32 stash)
+  const bool run_fwd = which & 1u, fwd_only = !(which & 2u);
+  launch_pack_x6(net, d_params, st, fast_bwd && run_fwd ? b.emax : nullptr);      // (also zeroes the forward kernel's row-gradient maximum)
   TrainArgsX a{};
   a.params = d_params; a.x = d_x; a.y = d_y; a.n_rows = n_rows; a.n_global = n_global; a.H = net->hidden; a.nh = net->n_hidden;
   a.drop = drop; a.b = b;
@@ -186,8 +200,6 @@ int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const fl
   *grid_out = grid;
   const __bf16* packed = (const __bf16*)net->d_packed;
   const bool bits = drop.mode == PINN_DROP_BITS;
-  const bool fast_bwd = net->precision == PINN_PREC_F32X6;           // backward chain in scheme X3 (PINN_PREC_F32X6_G6: x6)
-  const bool run_fwd = which & 1u, fwd_only = !(which & 2u);
   if (fast_bwd && !fwd_only && !run_fwd) {          // backward alone (per-kernel timing): no forward kernel has reset the maximum
     hipError_t em = hipMemsetAsync(b.amax, 0, sizeof(unsigned), st);
     if (em != hipSuccess) return (int)em;
@@ -195,11 +207,13 @@ int launch_train_chain_x6(const pinn_net_t* net, const float* d_params, const fl
 #define PINN_LAUNCH_T(HH, BB)                                                                                                   \
   do {                                                                                                                          \
     if (small_n) {                                                                                                              \
-      if (run_fwd) hipLaunchKernelGGL((train_fwd_x3_kernel<HH, BB, 4>), dim3(grid), dim3(256), 0, st, a, packed);               \
+      if (run_fwd && fast_bwd) hipLaunchKernelGGL((train_fwd_x3_kernel<HH, BB, 4, true>), dim3(grid), dim3(256), 0, st, a, packed);   \
+      else if (run_fwd) hipLaunchKernelGGL((train_fwd_x3_kernel<HH, BB, 4, false>), dim3(grid), dim3(256), 0, st, a, packed);   \
       if (!fwd_only && fast_bwd) hipLaunchKernelGGL((train_bwd_kernel<X3, HH, 4>), dim3(grid), dim3(256), 0, st, a, packed);    \
       else if (!fwd_only) hipLaunchKernelGGL((train_bwd_kernel<X6, HH, 4>), dim3(grid), dim3(256), 0, st, a, packed);           \
     } else {                                                                                                                    \
-      if (run_fwd) hipLaunchKernelGGL((train_fwd_x3_kernel<HH, BB, 8>), dim3(grid), dim3(512), 0, st, a, packed);               \
+      if (run_fwd && fast_bwd) hipLaunchKernelGGL((train_fwd_x3_kernel<HH, BB, 8, true>), dim3(grid), dim3(512), 0, st, a, packed);   \
+      else if (run_fwd) hipLaunchKernelGGL((train_fwd_x3_kernel<HH, BB, 8, false>), dim3(grid), dim3(512), 0, st, a, packed);   \
       if (!fwd_only && fast_bwd) hipLaunchKernelGGL((train_bwd_kernel<X3, HH, 8>), dim3(grid), dim3(512), 0, st, a, packed);    \
       else if (!fwd_only) hipLaunchKernelGGL((train_bwd_kernel<X6, HH, 8>), dim3(grid), dim3(512), 0, st, a, packed);           \
     }                                                                                                                           \

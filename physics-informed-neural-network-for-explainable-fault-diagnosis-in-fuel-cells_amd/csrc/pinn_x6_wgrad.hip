@@ -474,6 +474,290 @@ static void launch(const WgradArgs& a, int ns, hipStream_t st) {
   else hipLaunchKernelGGL((wgrad_x_kernel<TI, TJ, WI, WJ, 1>), grid, dim3(256), 0, st, a);
 }
 
+// ---------------------------------------------------------------------------------------
+// Packed operands (PINN_PREC_F32X6 on the fused nets): dW = dpre^T . h from the fragments the chain kernels stashed.
+//
+// A stash group (32 features x 16 rows) is a 2-KB block [part hi / lo][row][64 B]; a row's 64 B hold its 32 features as four
+// 16-B lane chunks of the chain's B fragment (packed_ptr, pinn_x6_core.h).  The weight gradient contracts over ROWS, so
+// it needs the transpose -- 8 rows of one feature per lane -- and gfx950 reads exactly that out of LDS:
+// ds_read_b64_tr_b16 hands each lane of a 16-lane group one 16-bit column of a 4-row block (tools/tr16_probe.hip pins
+// the lane map).  So: the blocks stream global -> LDS by LDS-DMA as they lie in memory (1 KB per instruction, fully
+// coalesced), four transposing reads per fragment give (hi, lo) x rows 8 hh .. 8 hh + 7 of feature tr_feature(lane & 31),
+// and no operand is split or shuffled in registers.  d pre-activations come in the rows' normalised units: the row scale
+// t_r = 2^(e_r - E + c) goes onto the OTHER operand, one v_pk_mul_f16 per dword (struct RowMeta / grad_exponent); bias and
+// predict-head sums are v_dot2_f32_f16 with the same row vectors.  Per 48 MFMAs: 32 + 32 (bias waves) VALU instructions,
+// where the split-in-registers kernel above needs 365.
+// ---------------------------------------------------------------------------------------
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_read_tr16(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+// lane i (0 .. 31) of a 32-feature tile holds feature tr_feature(i) of its group: 16-lane group x = i >> 4 reads the lane
+// chunks kq = 2 x, 2 x + 1; lane 4 p' + e of the group gets element e of 8-byte piece p' = 2 (kq & 1) + s, i.e. fragment
+// element 4 s + e = 2 r + b of chunk kq: feature 16 b + 4 kq + r
+__host__ __device__ inline int tr_feature(int i) {
+  const int x = i >> 4, p = (i >> 2) & 3, e = i & 3;
+  return 16 * (e & 1) + 4 * (2 * x + (p >> 1)) + 2 * (p & 1) + (e >> 1);
+}
+struct PFrag { u32x4 hi, lo; };            // 8 rows x (hi, lo) of one feature: dword k = rows 8 hh + 2 k, + 2 k + 1
+__device__ __forceinline__ u32x4 pk_mul4(const u32x4& v, const u32x4& t) {
+  u32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // (a vector ELEMENT handed to __builtin_bit_cast reads element 0 whatever k is, hipcc 7.2: go through scalars)
+    const unsigned vk = v[k], tk = t[k];
+    o[k] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, vk) * __builtin_bit_cast(f16x2, tk));
+  }
+  return o;
+}
+__device__ __forceinline__ float dot8(const u32x4& v, const u32x4& w, float acc) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned vk = v[k], wk = w[k];
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, vk), __builtin_bit_cast(f16x2, wk), acc, false);
+  }
+  return acc;
+}
+
+// A wave issues everything itself (one wave per SIMD: 256 accumulator registers), and an LDS-DMA instruction holds its issue
+// for 60-180 cycles: 17 of them in a burst at the top of a tile cost as much as the tile's 48 MFMAs (the first packed
+// version: 0.49 ms per 256 x 256 layer at 1e6 rows, against 0.54 split in registers -- the VALU work was gone, the burst
+// was not).  So the tile is cut into its TI x TJ blocks of three MFMAs and every block carries one DMA piece of tile t + 2
+// and, in the second half, its share of tile t + 1's transposing reads, pinned with sched_barrier: the pieces issue under
+// the matrix pipe's 96 cycles per block.
+template <int TI, int TJ, int WI, int WJ, bool kVQ, bool kVR>
+__global__ __launch_bounds__(256, 1) void wgrad_p_kernel(WgradPArgs a) {
+  constexpr int kFrags = TI + TJ, kBlocks = kFrags + (kVR ? TI : 0);      // 2-KB blocks per wave and tile: P, Q groups (+ R, fp32)
+  constexpr int kMetaAt = kBlocks * 2048, kStage = kMetaAt + 256;         // + the tile's row record
+  constexpr int kOps = 2 * kBlocks + 1;                                   // DMA instructions per tile
+  constexpr int NB = TI * TJ, kHalf = NB / 2;
+  constexpr int kPer = (kOps + NB - 1) / NB, kRd = (4 * kFrags + (NB - kHalf) - 1) / (NB - kHalf);
+  constexpr int kIssued = (kHalf + 1) * kPer < kOps ? (kHalf + 1) * kPer : kOps;      // this tile's pieces issued when the reads of the next start
+  extern __shared__ __attribute__((aligned(1024))) char ring_all[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave >= WI * WJ) return;
+  char* ring = ring_all + wave * 2 * kStage;
+  const int wi = wave / WJ, wj = wave % WJ;
+  const int hh = lane >> 5, i = lane & 31;
+  const int gi0 = blockIdx.y * (TI * WI) + wi * TI, gj0 = blockIdx.z * (TJ * WJ) + wj * TJ;      // first 32-feature group of P / of Q
+  const int i0 = 32 * gi0, j0 = 32 * gj0;
+  const bool row_sums = wj == 0 && blockIdx.z == 0, col_sums = wi == 0 && blockIdx.y == 0;
+  const bool want_q = kVQ && col_sums && a.dvq;
+  const int gP = a.OUT / 32, gQ = a.IN / 32;
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
+  double bsum[TI];
+  float vq[TJ], vr[TI];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) { bsum[ti] = 0.0; vr[ti] = 0.f; }
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) vq[tj] = 0.f;
+
+  const int slice = blockIdx.x;
+  const long long per = (a.t16 + a.n_slices - 1) / a.n_slices;
+  const long long t_begin = slice * per;
+  long long t_end = t_begin + per;
+  if (t_end > a.t16) t_end = a.t16;
+
+  // piece k of tile t: the hi (k even) or lo (k odd) KB of block k / 2 as it lies in memory (lane-linear 16 B per lane), the
+  // last one the tile's 256-B row record
+  struct Src { const char* p; const char* q; const char* r; const char* m; };
+  auto src_of = [&](long long t) {
+    return Src{a.P + ((t * gP + gi0) * 2048 + lane * 16), a.Q + ((t * gQ + gj0) * 2048 + lane * 16),
+               kVR ? (const char*)a.R + ((t * a.OUT + i0) * 64 + lane * 16) : nullptr, (const char*)a.meta + t * 256 + lane * 4};
+  };
+  auto piece = [&](const Src& s, char* st, auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k < 2 * kBlocks) {
+      constexpr int f = k / 2, half = k % 2;
+      const char* base = f < TI ? s.p + f * 2048 : (f < kFrags ? s.q + (f - TI) * 2048 : s.r + (f - kFrags) * 2048);
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + half * 1024), (lptr_t)(st + f * 2048 + half * 1024), 16, 0, PINN_WG_AUX);
+    } else {
+      __builtin_amdgcn_global_load_lds((gptr_t)s.m, (lptr_t)(st + kMetaAt), 4, 0, 0);
+    }
+  };
+  struct Regs {
+    u32x2 w[kFrags][4];                              // fragment f: hi rows 0-3, hi rows 4-7, lo rows 0-3, lo rows 4-7 (of 8 hh ..)
+    u32x4 tq, dh[kVQ ? 1 : 0], dl[kVQ ? 1 : 0];     // rows 8 hh .. 8 hh + 7: scales t_r; (kVQ) du_r norm_r as two fp16 parts
+    f32x4 rr[kVR ? TI : 0][2], s2[kVR ? 2 : 0];     // (kVR) fp32 operands of the vector-head sum: R rows, dz
+  };
+  // transposing reads: lane 4 q' + p' of a 16-lane group addresses (row q' of the 4-row block, 8-byte piece p'); one base
+  // register, everything else in the instruction's offset field
+  const int L = lane & 15;
+  const unsigned lane_off = (unsigned)((8 * hh + (L >> 2)) * 64 + (2 * ((lane >> 4) & 1) + ((L & 3) >> 1)) * 16 + (L & 1) * 8);
+  auto read_one = [&](Regs& r, unsigned base, auto jc) {
+    constexpr int j = decltype(jc)::value, f = j / 4, sub = j % 4;
+    r.w[f][sub] = lds_read_tr16<f * 2048 + (sub >> 1) * 1024 + (sub & 1) * 256>(base);
+  };
+  auto read_side = [&](Regs& r, const char* st) {
+    const char* m = st + kMetaAt + 16 * hh;
+    r.tq = *reinterpret_cast<const u32x4*>(m);
+    if constexpr (kVQ) {
+      r.dh[0] = *reinterpret_cast<const u32x4*>(m + 32);
+      r.dl[0] = *reinterpret_cast<const u32x4*>(m + 64);
+    }
+    if constexpr (kVR) {
+      r.s2[0] = *reinterpret_cast<const f32x4*>(st + kMetaAt + 128 + 32 * hh);
+      r.s2[1] = *reinterpret_cast<const f32x4*>(st + kMetaAt + 128 + 32 * hh + 16);
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        r.rr[ti][0] = *reinterpret_cast<const f32x4*>(st + (kFrags + ti) * 2048 + i * 64 + 32 * hh);
+        r.rr[ti][1] = *reinterpret_cast<const f32x4*>(st + (kFrags + ti) * 2048 + i * 64 + 32 * hh + 16);
+      }
+    }
+  };
+  auto frag_hi = [](const Regs& r, int f) { return u32x4{r.w[f][0][0], r.w[f][0][1], r.w[f][1][0], r.w[f][1][1]}; };
+  auto frag_lo = [](const Regs& r, int f) { return u32x4{r.w[f][2][0], r.w[f][2][1], r.w[f][3][0], r.w[f][3][1]}; };
+
+  if (t_begin < t_end) {
+    auto clampt = [&](long long t) { return t < t_end ? t : t_end - 1; };
+    Regs cur, nxt;
+    {
+      const Src s0 = src_of(t_begin), s1 = src_of(clampt(t_begin + 1));
+      static_for<kOps>([&](auto kc) { piece(s0, ring, kc); });
+      static_for<kOps>([&](auto kc) { piece(s1, ring + kStage, kc); });
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps) : "memory");       // tile t_begin has landed
+      const unsigned base = (unsigned)(unsigned long long)(lptr_t)ring + lane_off;
+      static_for<4 * kFrags>([&](auto jc) { read_one(cur, base, jc); });
+      read_side(cur, ring);
+    }
+    for (long long t = t_begin; t < t_end; ++t) {
+      const int s0 = (int)((t - t_begin) & 1);
+      // stage s0 (tile t) is in registers: it takes tile t + 2, piece by piece under the MFMAs; the other stage (tile t + 1)
+      // has landed once all but this tile's own pieces are through
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // ... the LDS reads of `cur` are done
+      __builtin_amdgcn_sched_barrier(0);
+      const Src sn = src_of(clampt(t + 2));
+      char* st_fill = ring + s0 * kStage;
+      const char* st_next = ring + (s0 ^ 1) * kStage;
+      const unsigned base_next = (unsigned)(unsigned long long)(lptr_t)st_next + lane_off;
+      u32x4 qh[TJ], ql[TJ];
+      static_for<NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value, ti = b / TJ, tj = b % TJ;
+        if constexpr (ti == 0) {      // the row scale onto this Q fragment, at its first use
+          qh[tj] = pk_mul4(frag_hi(cur, TI + tj), cur.tq);
+          ql[tj] = pk_mul4(frag_lo(cur, TI + tj), cur.tq);
+        }
+        const u32x4 ph = frag_hi(cur, ti), pl = frag_lo(cur, ti);
+#ifdef PINN_ABL_WGP_NOMFMA      // (ablation builds, tools/build_variant.py: what the tile costs without its matrix work)
+        asm volatile("" ::"v"(ph), "v"(pl), "v"(qh[tj]), "v"(ql[tj]));
+#else
+        acc[ti][tj] = PINN_MFMA32_F16(__builtin_bit_cast(f16x8, pl), __builtin_bit_cast(f16x8, qh[tj]), acc[ti][tj]);      // smallest first
+        acc[ti][tj] = PINN_MFMA32_F16(__builtin_bit_cast(f16x8, ph), __builtin_bit_cast(f16x8, ql[tj]), acc[ti][tj]);
+        acc[ti][tj] = PINN_MFMA32_F16(__builtin_bit_cast(f16x8, ph), __builtin_bit_cast(f16x8, qh[tj]), acc[ti][tj]);
+#endif
+#ifndef PINN_ABL_WGP_NODMA
+        static_for<kPer>([&](auto ic) {
+          constexpr int k = b * kPer + decltype(ic)::value;
+          if constexpr (k < kOps) piece(sn, st_fill, IC<k>{});
+        });
+#endif
+        if constexpr (b == kHalf) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kIssued) : "memory");
+#ifndef PINN_ABL_WGP_NOREAD
+          read_side(nxt, st_next);
+#endif
+        }
+#ifndef PINN_ABL_WGP_NOREAD
+        if constexpr (b >= kHalf) {
+          static_for<kRd>([&](auto ic) {
+            constexpr int j = (b - kHalf) * kRd + decltype(ic)::value;
+            if constexpr (j < 4 * kFrags) read_one(nxt, base_next, IC<j>{});
+          });
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if (row_sums) {          // bias: sum_r d pre_r = 2^(E - c - 4) sum_r p_r t_r
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) bsum[ti] += (double)dot8(frag_hi(cur, ti), cur.tq, dot8(frag_lo(cur, ti), cur.tq, 0.0f));
+        if constexpr (kVR) {
+          if (a.dvr) {
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+              for (int ti = 0; ti < TI; ++ti) {
+                const f32x4 sv = cur.s2[sg], rv = cur.rr[ti][sg];
+                vr[ti] += (sv[0] * rv[0] + sv[1] * rv[1]) + (sv[2] * rv[2] + sv[3] * rv[3]);
+              }
+          }
+        }
+      }
+      if constexpr (kVQ) {
+        if (want_q) {          // predict head: sum_r du_r h_r = 2^(E - c - 7) sum_r (du_r norm_r) (8 h_r t_r)
+#pragma unroll
+          for (int tj = 0; tj < TJ; ++tj) vq[tj] += dot8(qh[tj], cur.dh[0], dot8(ql[tj], cur.dh[0], dot8(qh[tj], cur.dl[0], 0.0f)));
+        }
+      }
+#ifndef PINN_ABL_WGP_NOREAD
+      cur = nxt;
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing re-fetches must land before the LDS is released
+  }
+
+  // ---- write this slice's slab; the powers of two of the row scale leave here
+  const int E = grad_exponent(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(*a.emax)), 4);
+  const float sw = ldexpf(1.0f, E - a.qboost - 7), sb = ldexpf(1.0f, E - a.qboost - 4);
+  const long long so = (long long)slice * a.slab_stride;
+  const int fi = tr_feature(i);
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+      const int col = j0 + tj * 32 + fi;           // input feature (C/D layout: B's lane = column)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + ti * 32 + tr_feature((r & 3) + 8 * (r >> 2) + 4 * hh);      // A's lane = row of the tile
+        a.dW[so + (long long)row * a.IN + col] = acc[ti][tj][r] * sw;
+      }
+    }
+  if (row_sums) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      const double bb = bsum[ti] + __shfl_xor(bsum[ti], 32, 64);
+      if (hh == 0) a.db[so + i0 + ti * 32 + fi] = (float)(bb * (double)sb);
+      if constexpr (kVR) {
+        if (a.dvr) {
+          const float v = vr[ti] + __shfl_xor(vr[ti], 32, 64);
+          if (hh == 0) a.dvr[so + i0 + ti * 32 + i] = v;       // (R is fp32 in the natural feature order)
+        }
+      }
+    }
+  }
+  if constexpr (kVQ) {
+    if (want_q) {
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj) {
+        const float v = vq[tj] + __shfl_xor(vq[tj], 32, 64);
+        if (hh == 0) a.dvq[so + j0 + tj * 32 + fi] = v * sw;
+      }
+    }
+  }
+}
+
+template <int TI, int TJ, int WI, int WJ, bool kVQ = false, bool kVR = false>
+static int launch_p(const WgradPArgs& a, hipStream_t st) {
+  const dim3 grid(a.n_slices, a.OUT / (TI * 32 * WI), a.IN / (TJ * 32 * WJ));
+  const size_t lds = (size_t)WI * WJ * 2 * ((TI + TJ + (kVR ? TI : 0)) * 2048 + 256);
+  auto k = wgrad_p_kernel<TI, TJ, WI, WJ, kVQ, kVR>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+  return PINN_OK;
+}
+
 }  // namespace x6
 
 // [OUT x IN] gradient with IN a multiple of 32 (every layer but the input one); ns = the operand split (4: two fp16 parts,
@@ -500,6 +784,28 @@ int dispatch_wgrad_x6(const WgradArgs& a, int ns, void* stream) {
   else if (to % 4 == 0 && ti % 8 == 0) launch<2, 4, 2, 2>(a, ns, st);        //            blocks of 128 x 256
   else return PINN_E_ARCH;
   return PINN_OK;
+}
+
+// the packed form of the same gradients (PINN_PREC_F32X6, fused nets)
+int dispatch_wgrad_p(const WgradPArgs& a, void* stream) {
+  using namespace x6;
+  hipStream_t st = (hipStream_t)stream;
+  const int to = a.OUT / 32, ti = a.IN / 32;
+  if (!a.P || !a.Q || !a.meta || !a.emax || a.IN % 32 || a.OUT % 32) return PINN_E_ARG;
+  if (a.dvq) {                     // variance head layer 0 (+ the predict head's weight): H = 256 / 128
+    if (to == 4 && ti == 8) return launch_p<2, 4, 2, 2, true>(a, st);
+    if (to == 2 && ti == 4) return launch_p<1, 2, 2, 2, true>(a, st);
+    return PINN_E_ARCH;
+  }
+  if (a.dvr) {                     // variance head layer 1 (+ the head's last weight, fp32 operands): H = 256 / 128
+    if (!a.R || !a.s2) return PINN_E_ARG;
+    if (to == 2 && ti == 4) return launch_p<1, 2, 2, 2, false, true>(a, st);
+    if (to == 1 && ti == 2) return launch_p<1, 1, 1, 2, false, true>(a, st);
+    return PINN_E_ARCH;
+  }
+  if (to == 8 && ti == 8) return launch_p<4, 4, 2, 2>(a, st);
+  if (to == 4 && ti == 4) return launch_p<2, 2, 2, 2>(a, st);
+  return PINN_E_ARCH;
 }
 
 }  // namespace pinn

@@ -101,8 +101,8 @@ def train_grads(lib, H, nh, fp, x, y, drop=None, n_global=None, precision=0):
     N = x.shape[0]
     net = make_net(lib, H, nh, precision)
     wb = lib.pinn_train_workspace_bytes(ctypes.byref(net), N)
-    work = torch.empty(wb, dtype=torch.uint8, device=dev())
-    grads = torch.full((fp.numel(),), float("nan"), device=dev())
+    work = torch.full((wb,), 0xFF, dtype=torch.uint8, device=dev())      # poisoned: every fp32 / fp16 word a NaN, so a read of anything the call
+    grads = torch.full((fp.numel(),), float("nan"), device=dev())      # did not write first shows in the result
     loss = torch.zeros(4, dtype=torch.float64, device=dev())
     _lib.check(lib.pinn_mlp_train_grads(ctypes.byref(net), ptr(fp), ptr(x), ptr(y), N, n_global or N,
                                         ctypes.byref(drop) if drop is not None else None, ptr(grads), ptr(loss), ptr(work), wb,
