@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PINN_ABI_VERSION 1
+#define PINN_ABI_VERSION 2   /* 2: pinn_dropout_t.d_step_counter, pinn_adam_step_dev, pinn_net_range_status; precision code 3 = F32X6_G6 */
 
 /* error codes (negative; positive values are hipError_t) */
 #define PINN_OK 0
@@ -206,6 +206,10 @@ typedef struct pinn_dropout {
   long long row_offset;       /* global index of local row 0 (data-parallel shards) */
   const unsigned* d_bits;     /* BITS: [n_passes][n_rows][words] uint32, bit f of module l at
                                  word offset l*(H/32) (+ f/32), words = n_hidden*H/32 + H/64 */
+  unsigned* d_step_counter;   /* NULL, or (pinn_mlp_train_grads on the fused nets, hidden <= 256) a device counter of completed
+                                 optimizer steps: the call draws PHILOX stream `stream + *d_step_counter` (BITS: pass
+                                 *d_step_counter of d_bits) and adds 1 to the counter when its gradients are final -- so ONE
+                                 captured launch sequence (a hipGraph) can be replayed step after step; see pinn_adam_step_dev */
 } pinn_dropout_t;
 
 /* DNN.forward (01:421-438): d_u, d_logvar [n_rows]. */
@@ -235,10 +239,21 @@ int pinn_mlp_train_grads(const pinn_net_t* net, const float* d_params, const flo
 #define PINN_PHASE_WGRAD 2u   /* the per-layer weight-gradient kernels (read the stash)              */
 #define PINN_PHASE_REDUCE 4u  /* fixed-order slab reduction -> d_grads, d_loss                       */
 #define PINN_PHASE_ALL 7u
-/* PINN_PREC_F32X6 / _G3 on the fused nets (hidden <= 256): the chain is two kernels, forward (+ loss) and backward; either
+/* PINN_PREC_F32X6 / _G6 on the fused nets (hidden <= 256): the chain is two kernels, forward (+ loss) and backward; either
  * alone (the other precisions and the wide nets treat these two bits like PINN_PHASE_CHAIN) */
 #define PINN_PHASE_CHAIN_FWD 8u
 #define PINN_PHASE_CHAIN_BWD 16u
+/* Two-part form of the weight-gradient and reduction phases, for overlapping the data-parallel all-reduce with the rest of
+ * the step: the flat gradient splits at pinn_grad_split(net) floats into a HEAD [0, split) -- the input layer and every hidden
+ * layer but the last -- and a TAIL [split, n) -- the last hidden layer, the predict head and the variance head, whose d
+ * pre-activations the backward chain finishes first.  _TAIL / _HEAD run the weight-gradient kernels (the slab reduction) of
+ * that part only; PINN_PHASE_WGRAD / _REDUCE are both parts.  pinn_grad_split is 0 (everything is "tail") where the
+ * precision's kernels do not split (PINN_PREC_BF16 on the fused nets). */
+#define PINN_PHASE_WGRAD_TAIL 32u
+#define PINN_PHASE_WGRAD_HEAD 64u
+#define PINN_PHASE_REDUCE_TAIL 128u
+#define PINN_PHASE_REDUCE_HEAD 256u
+long long pinn_grad_split(const pinn_net_t* net);
 int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y,
                                 long long n_rows, long long n_global, const pinn_dropout_t* drop,
                                 float* d_grads, double* d_loss, void* d_work, size_t work_bytes, void* stream,
@@ -247,6 +262,15 @@ int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d_params, co
 /* torch.optim.Adam defaults (01:939): flat vectors of n floats; step is 1-based. */
 int pinn_adam_step(float* d_params, const float* d_grads, float* d_m, float* d_v, long long n,
                    float lr, int step, void* stream);
+
+/* The same step with its two scalars read on the DEVICE, for a captured (hipGraph) training step that is replayed with
+ * nothing but device state changing (train_dnn at the reference's data sizes is launch-bound: 01:939-955, 12 002 steps of
+ * ~1e4 rows).  d_coeffs: float[2 * n_steps], entry k = the coefficients of step k + 1 as pinn_adam_coeffs gives them (the host
+ * arithmetic of pinn_adam_step, so both paths are bit-identical); d_step_counter: the counter pinn_mlp_train_grads advanced
+ * (pinn_dropout_t.d_step_counter): this call applies entry *d_step_counter - 1. */
+void pinn_adam_coeffs(float lr, int step, float* step_size, float* bc2_sqrt);      /* host only */
+int pinn_adam_step_dev(float* d_params, const float* d_grads, float* d_m, float* d_v, long long n,
+                       const float* d_coeffs, const unsigned* d_step_counter, void* stream);
 
 /* ---- results assembly: create_comprehensive_results_array_v2 (01:1877-2010) -----------------------------------
  * Fills d_out = float64 [n_rows, 22] row-major (the `comprehensive_results` layout scripts 02-05 read):

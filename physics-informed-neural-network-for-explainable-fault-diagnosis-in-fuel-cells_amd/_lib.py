@@ -33,6 +33,8 @@ class Affine(ctypes.Structure):
 
 
 PREC_FP32, PREC_BF16, PREC_F32X6, PREC_F32X6_G6 = 0, 1, 2, 3
+PHASE_CHAIN, PHASE_WGRAD, PHASE_REDUCE, PHASE_ALL = 1, 2, 4, 7
+PHASE_WGRAD_TAIL, PHASE_WGRAD_HEAD, PHASE_REDUCE_TAIL, PHASE_REDUCE_HEAD = 32, 64, 128, 256
 STAGE_RUN_MAX_ROWS, STAGE_LOG_FLOATS = 65536, 64
 
 
@@ -45,7 +47,7 @@ class Net(ctypes.Structure):
 
 class Dropout(ctypes.Structure):
     _fields_ = [("mode", c_int), ("p", c_float * 9), ("seed", ctypes.c_ulonglong), ("stream", c_uint),
-                ("row_offset", c_ll), ("d_bits", c_void_p)]
+                ("row_offset", c_ll), ("d_bits", c_void_p), ("d_step_counter", c_void_p)]
 
 
 class PinnError(RuntimeError):
@@ -76,11 +78,14 @@ _SIGS = {
     "pinn_mc_dropout": (c_int, [ctypes.POINTER(Net), c_void_p, c_void_p, c_ll, ctypes.POINTER(Dropout), c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
     "pinn_train_workspace_bytes": (c_size_t, [ctypes.POINTER(Net), c_ll]),
+    "pinn_grad_split": (c_ll, [ctypes.POINTER(Net)]),
     "pinn_mlp_train_grads": (c_int, [ctypes.POINTER(Net), c_void_p, c_void_p, c_void_p, c_ll, c_ll, ctypes.POINTER(Dropout),
                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pinn_mlp_train_grads_phases": (c_int, [ctypes.POINTER(Net), c_void_p, c_void_p, c_void_p, c_ll, c_ll, ctypes.POINTER(Dropout),
                                             c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_uint]),
     "pinn_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_int, c_void_p]),
+    "pinn_adam_coeffs": (None, [c_float, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
+    "pinn_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p]),
     "pinn_residuals_prepare": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(Affine), c_void_p, c_uint, c_ll, c_void_p, c_void_p]),
     "pinn_residuals_cached": (c_int, [c_void_p, ctypes.POINTER(Affine), c_void_p, c_uint, c_ll, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pinn_net_f_t": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Affine), c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
@@ -124,7 +129,7 @@ def load(build_if_missing=True):
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.pinn_abi_version() != 1:
+    if lib.pinn_abi_version() != 2:
         raise PinnError("libpinn_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(kThreads, 2) void train_chain_bf16_kernel(TrainArgs
   __bf16* const dpre_v2 = (__bf16*)a.b.dpre_v2;
 
   const long long n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
+  const unsigned pass0 = train_pass(a.drop);      // 0, or the device's step counter (replayed graphs)
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long t16 = tile * 4 + wave;
     const long long lrow = t16 * 16 + (lane & 15);
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(kThreads, 2) void train_chain_bf16_kernel(TrainArgs
     const f32x4 xa = reinterpret_cast<const f32x4*>(a.x)[srow * 2];
     const f32x4 xb = reinterpret_cast<const f32x4*>(a.x)[srow * 2 + 1];
     const float yv = a.y[srow];
-    const RowCtx c{lane, kq, a.drop.row_offset + lrow, srow, a.n_rows, 0u, a.drop.mode};
+    const RowCtx c{lane, kq, a.drop.row_offset + lrow, srow, a.n_rows, pass0, a.drop.mode};
     const StashPtrsBf16 st{stash_h, stash_v1, stash_v2, a.b.keep, a.b.t16, t16};
     const unsigned char* keep = a.b.keep + (t16 * n_groups) * 64 + lane;
 

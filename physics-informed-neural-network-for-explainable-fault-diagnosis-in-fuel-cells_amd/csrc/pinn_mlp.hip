@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(FwdArgs a) {
 static int convert_drop(const pinn_net_t* net, const pinn_dropout_t* in, DropDev* out) {
   out->mode = PINN_DROP_NONE;
   out->bits = nullptr; out->words = 0; out->nb = net->hidden / 32;
-  out->seed_lo = out->seed_hi = 0; out->stream = 0; out->row_offset = 0;
+  out->seed_lo = out->seed_hi = 0; out->stream = 0; out->row_offset = 0; out->step_counter = nullptr;
   for (int l = 0; l < kMaxDrop; ++l) { out->thr[l] = 0; out->scale[l] = 1.0f; }
   if (!in) return PINN_OK;
   if (in->mode < PINN_DROP_NONE || in->mode > PINN_DROP_BITS) return PINN_E_ARG;

@@ -107,7 +107,13 @@ struct DropDev {
   const unsigned* bits;
   int words;                  // uint32 words per row-pass of injected masks
   int nb;                     // words per hidden-layer mask (H / 32)
+  unsigned* step_counter;     // training calls only (pinn_dropout_t.d_step_counter): device count of completed optimizer steps = this
+                              // call's pass index (Philox stream `stream + pass`, injected masks: pass `pass` of `bits`); or nullptr
 };
+// pass index of a training call (RowCtx::pass): 0, or the device's step counter for replayed graphs
+__device__ __forceinline__ unsigned train_pass(const DropDev& d) {
+  return d.step_counter ? __builtin_amdgcn_readfirstlane(*d.step_counter) : 0u;
+}
 
 // The round keys are wave-uniform (key + round * Weyl constant: scalar unit) and each counter update is one three-input XOR
 // (v_bitop3_b32, truth table 0x96): 20 multiplies + 20 XORs per call.

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(kThreads, 2) void train_chain_kernel(TrainArgs a) {
   float s_nll = 0.f, s_abs = 0.f, s_mse = 0.f, s_du = 0.f, s_dz = 0.f;
 
   const long long n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
+  const unsigned pass0 = train_pass(a.drop);      // 0, or the device's step counter (replayed graphs)
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long t16 = tile * 4 + wave;
     const long long lrow = t16 * 16 + (lane & 15);
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(kThreads, 2) void train_chain_kernel(TrainArgs a) {
     const f32x4 xa = reinterpret_cast<const f32x4*>(a.x)[srow * 2];
     const f32x4 xb = reinterpret_cast<const f32x4*>(a.x)[srow * 2 + 1];
     const float yv = a.y[srow];
-    const RowCtx c{lane, kq, a.drop.row_offset + lrow, srow, a.n_rows, 0u, a.drop.mode};
+    const RowCtx c{lane, kq, a.drop.row_offset + lrow, srow, a.n_rows, pass0, a.drop.mode};
     const StashPtrs st{a.stash_h, a.stash_v1, a.stash_v2, a.keep, a.t16, t16};
     const unsigned char* keep = a.keep + (t16 * n_groups) * 64 + lane;
 
@@ -427,17 +428,23 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
                                                             const double* __restrict__ loss_part, int n_parts,
                                                             long long off_bp, long long off_bv2, float* __restrict__ grads,
                                                             double* __restrict__ loss_out, const unsigned* __restrict__ amax,
-                                                            unsigned* __restrict__ range_word) {
+                                                            unsigned* __restrict__ range_word, unsigned* __restrict__ step_counter,
+                                                            long long e_lo, long long e_hi, int with_loss) {
+  // [e_lo, e_hi): the part of the flat gradient this launch reduces (multiples of 4; the whole vector, or the head / the tail
+  // of pinn_grad_split); with_loss: the launch that also owns the loss sums, the range record and the step counter (the tail)
   __shared__ f64x4 part[kFinLanes][kFinGroups];
   // pinn_net_range_status: the X3 backward chain's largest |d pre-activation| of this call is inf once a row-normalised
   // gradient has left fp16's range (a NaN alone does not move the maximum, but then the gradients are NaN: visible)
-  if (range_word && blockIdx.x == 0 && threadIdx.x == 0 && (*amax & 0x7FFFFFFFu) >= 0x7F800000u) *range_word = 1u;
+  if (with_loss && range_word && blockIdx.x == 0 && threadIdx.x == 0 && (*amax & 0x7FFFFFFFu) >= 0x7F800000u) *range_word = 1u;
+  // pinn_dropout_t.d_step_counter: the gradients of this step are final with this launch; every kernel that read the counter
+  // (the chain's dropout pass) ran before it, the optimizer step that reads it next runs behind it
+  if (with_loss && step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1u;
   const int g = threadIdx.x & (kFinGroups - 1), q = threadIdx.x / kFinGroups;
   // every tensor starts on a multiple of 4 floats, so the two scalar head biases sit at the start of a group whose other
   // three floats are padding
-  const long long e = 4 * ((long long)blockIdx.x * kFinGroups + g);
+  const long long e = e_lo + 4 * ((long long)blockIdx.x * kFinGroups + g);
   f64x4 s = {0.0, 0.0, 0.0, 0.0};
-  if (e < total) {
+  if (e < e_hi) {
     int k = q;
     for (; k + 7 * kFinLanes < n_slices; k += 8 * kFinLanes) {
       f32x4 v[8];
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
   }
   part[q][g] = s;
   __syncthreads();
-  if (q == 0 && e < total) {
+  if (q == 0 && e < e_hi) {
     if (e == off_bp || e == off_bv2) {
       grads[e + 1] = 0.0f; grads[e + 2] = 0.0f; grads[e + 3] = 0.0f;       // [e] itself: the loss-sum block below
     } else {
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
       *reinterpret_cast<f32x4*>(grads + e) = f32x4{(float)s[0], (float)s[1], (float)s[2], (float)s[3]};
     }
   }
-  if (blockIdx.x == 0) {
+  if (blockIdx.x == 0 && with_loss) {
     // the chain's per-workgroup loss partials (<= 1024 x kLossTerms doubles): strided over the 256 threads, then a fixed
     // shuffle / LDS tree (one thread walking them serially cost ~50 us of dependent L2 latency)
     __shared__ double lred[4][kLossTerms];
@@ -481,6 +488,27 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
     }
   }
 }
+
+constexpr long long kFanOutT16 = 2048;       // row tiles below which the weight-gradient launches fan out over side streams
+
+// Side streams for the independent weight-gradient launches of one step at small row counts.  Fork / join with events on the
+// caller's stream, so the pattern is legal inside a stream capture (model.train_dnn replays the step as a hipGraph, where the
+// branches cost nothing on the host); created at the first small call.  One process drives one GPU (pinn_hip.h).
+struct FanOut {
+  hipStream_t side[3];
+  hipEvent_t fork, join[3];
+  bool ok = false;
+  bool init() {
+    if (ok) return true;
+    for (int i = 0; i < 3; ++i) {
+      if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) return false;
+      if (hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return false;
+    }
+    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
+    return ok = true;
+  }
+};
+static FanOut g_fan;
 
 struct Workspace {
   long long t16;
@@ -510,7 +538,12 @@ static Workspace plan_workspace(const pinn_net_t* net, long long n_rows) {
   w.off_amax = take(256);                                   // [0] TrainBuffers::amax, [1] ::emax
   w.off_rowmeta = take((size_t)w.t16 * 256);                // struct RowMeta records
   const long long t32 = (w.t16 + 1) / 2;
-  w.n_slices = (int)(t32 < kMaxSlices ? (t32 < 1 ? 1 : t32) : kMaxSlices);
+  // slices = workgroups per weight-gradient launch = slabs the reduction adds.  Large row counts: one per CU.  The reference's
+  // own sizes (< 32 768 rows) are bound by the slabs instead -- at 1e4 rows 256 slices wrote 67 MB per 256 x 256 layer and the
+  // reduction read 180 MB, 100 of the step's 200 us --: 64 slices there, and the five layers' launches run side by side
+  // (fan_out below), 320 workgroups in all
+  const long long cap = w.t16 < kFanOutT16 ? 64 : kMaxSlices;
+  w.n_slices = (int)(t32 < cap ? (t32 < 1 ? 1 : t32) : cap);
   ParamLayout L{(int)H, (int)nh};
   w.off_slabs = take((size_t)w.n_slices * L.total() * 4);
   w.total = o;
@@ -589,6 +622,13 @@ int dispatch_wgrad_p(const WgradPArgs& a, void* stream);            // pinn_x6_w
 
 using namespace pinn;
 
+extern "C" long long pinn_grad_split(const pinn_net_t* net) {
+  if (check_net_t(net) != PINN_OK) return -1;
+  if (net->precision == PINN_PREC_BF16 && net->hidden <= 256) return 0;      // the fused bf16 family launches its weight gradients as one block
+  ParamLayout L{net->hidden, net->n_hidden};
+  return net->n_hidden >= 2 ? L.w(net->n_hidden - 1) : L.wp();
+}
+
 extern "C" size_t pinn_train_workspace_bytes(const pinn_net_t* net, long long n_rows) {
   if (check_net_t(net) != PINN_OK || n_rows < 0) return 0;
   return plan_workspace(net, n_rows).total;
@@ -604,6 +644,15 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
   // the forward / backward halves are separate kernels only in the fused x6 path; elsewhere either bit means the chain
   if (!(net->precision >= PINN_PREC_F32X6 && net->hidden <= 256) && (phases & (PINN_PHASE_CHAIN_FWD | PINN_PHASE_CHAIN_BWD)))
     phases |= PINN_PHASE_CHAIN;
+  // two-part weight gradients / reduction (pinn_grad_split): the single-part bits mean both parts; a precision whose kernels do
+  // not split keeps everything in the "tail"
+  if (phases & PINN_PHASE_WGRAD) phases |= PINN_PHASE_WGRAD_TAIL | PINN_PHASE_WGRAD_HEAD;
+  if (phases & PINN_PHASE_REDUCE) phases |= PINN_PHASE_REDUCE_TAIL | PINN_PHASE_REDUCE_HEAD;
+  const long long split = pinn_grad_split(net);
+  if (split == 0) {
+    phases = (phases & ~(PINN_PHASE_WGRAD | PINN_PHASE_REDUCE)) | ((phases & PINN_PHASE_WGRAD_TAIL) ? PINN_PHASE_WGRAD : 0u) |
+             ((phases & PINN_PHASE_REDUCE_TAIL) ? PINN_PHASE_REDUCE : 0u);
+  }
   const Workspace w = plan_workspace(net, n_rows);
   if (work_bytes < w.total) return PINN_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -618,10 +667,12 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
   {
     DropDev& d = a.drop;
     d.mode = PINN_DROP_NONE; d.bits = nullptr; d.words = 0; d.nb = H / 32; d.seed_lo = d.seed_hi = 0; d.stream = 0; d.row_offset = 0;
+    d.step_counter = nullptr;
     for (int l = 0; l < kMaxDrop; ++l) { d.thr[l] = 0; d.scale[l] = 1.0f; }
     if (drop) {
       if (drop->mode < PINN_DROP_NONE || drop->mode > PINN_DROP_BITS) return PINN_E_ARG;
-      d.mode = drop->mode; d.row_offset = drop->row_offset;
+      if (drop->d_step_counter && H > 256) return PINN_E_ARCH;      // the layer-by-layer kernels take their pass index by value
+      d.mode = drop->mode; d.row_offset = drop->row_offset; d.step_counter = drop->d_step_counter;
       if (drop->mode != PINN_DROP_NONE) {
         for (int l = 0; l <= nh; ++l) {
           const float p = drop->p[l];
@@ -657,7 +708,8 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     if ((rc = launch_train_bf16(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, phases, &grid, stream))) return rc;
     if (phases & PINN_PHASE_REDUCE)
       hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((L.total() / 4 + kFinGroups - 1) / kFinGroups)), dim3(256), 0, st, b.slabs, w.n_slices,
-                         L.total(), a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss, (const unsigned*)nullptr, (unsigned*)nullptr);
+                         L.total(), a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss, (const unsigned*)nullptr, (unsigned*)nullptr, a.drop.step_counter,
+                         0LL, (long long)L.total(), 1);
     hipError_t eb = hipGetLastError();
     return eb == hipSuccess ? PINN_OK : (int)eb;
   }
@@ -696,14 +748,29 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
   float* slabs = (float*)(base + w.off_slabs);
   const long long tot = L.total();
   const long long hs = (long long)w.t16 * H * 16;   // floats per hidden-layer stash
-  if (phases & PINN_PHASE_WGRAD) {
+  if (phases & (PINN_PHASE_WGRAD_TAIL | PINN_PHASE_WGRAD_HEAD)) {
+    // tail = the layers whose d pre-activations the backward chain finishes first (last hidden layer, heads); head = the rest
+    const bool do_tail = phases & PINN_PHASE_WGRAD_TAIL, do_head = phases & PINN_PHASE_WGRAD_HEAD;
+    auto in_part = [&](int l) { return l == nh - 1 ? do_tail : do_head; };      // hidden layer l >= 1
+    // small row counts: the launches of the layers are independent and short -- side by side on up to four streams
+    const bool fan = w.t16 < kFanOutT16 && g_fan.init();
+    int n_launch = 0;
+    bool used[3] = {false, false, false};
+    if (fan && hipEventRecord(g_fan.fork, st) != hipSuccess) return (int)hipGetLastError();
+    auto pick = [&]() -> hipStream_t {
+      if (!fan) return st;
+      const int k = n_launch++ % 4;
+      if (k == 0) return st;
+      if (!used[k - 1]) { (void)hipStreamWaitEvent(g_fan.side[k - 1], g_fan.fork, 0); used[k - 1] = true; }
+      return g_fan.side[k - 1];
+    };
     WgradArgs g{};
     g.x = d_x; g.n_rows = n_rows; g.t16 = w.t16; g.n_slices = w.n_slices; g.slab_stride = tot;
     g.amax = (const unsigned*)(base + w.off_amax);
     // layer 0: dW0 = dpre_0 x^T
     g.P = a.dpre_h; g.Q = nullptr; g.OUT = H; g.IN = 8; g.dW = slabs + L.w0(); g.db = slabs + L.b0();
     g.s1 = nullptr; g.dvq = nullptr; g.s2 = nullptr; g.R = nullptr; g.dvr = nullptr;
-    if ((rc = dispatch_wgrad(g, st))) return rc;
+    if (do_head) { if ((rc = dispatch_wgrad(g, pick()))) return rc; }
     // every layer but the input one: split-bf16 products on the matrix cores for PINN_PREC_F32X6
     // operand split of the weight-gradient kernels: 0 = exact fp32 kernels; 3 = three bf16 parts, six products (x6); 4 = two fp16
     // parts under the common scale the X3 backward kernels measured (PINN_PREC_F32X6); 1 = bf16-mixed (wide nets)
@@ -713,42 +780,57 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
       p.meta = base + w.off_rowmeta; p.emax = (const unsigned*)(base + w.off_amax) + 1; p.qboost = row_scale_boost(a.drop, nh);
       p.t16 = w.t16; p.n_slices = w.n_slices; p.slab_stride = tot;
       const long long hb = hs * 4;      // bytes per hidden-layer stash
-      for (int l = 1; l < nh; ++l) {
+      for (int l = nh - 1; l >= 1; --l) {
+        if (!in_part(l)) continue;
         p.P = (const char*)a.dpre_h + l * hb; p.Q = (const char*)a.stash_h + (l - 1) * hb; p.OUT = H; p.IN = H; p.dW = slabs + L.w(l); p.db = slabs + L.b(l);
-        if ((rc = dispatch_wgrad_p(p, stream))) return rc;
+        if ((rc = dispatch_wgrad_p(p, (void*)pick()))) return rc;
       }
-      // variance head layer 0 (+ predict weight: dw_p[j] = sum du * h_last[j])
-      p.P = (const char*)a.dpre_v1; p.Q = (const char*)a.stash_h + (nh - 1) * hb; p.OUT = H / 2; p.IN = H; p.dW = slabs + L.wv0(); p.db = slabs + L.bv0();
-      p.dvq = slabs + L.wp();
-      if ((rc = dispatch_wgrad_p(p, stream))) return rc;
-      // variance head layer 1 (+ final weight: dwv2[i] = sum dz * v2[i], fp32 operands)
-      p.P = (const char*)a.dpre_v2; p.Q = (const char*)a.stash_v1; p.OUT = H / 4; p.IN = H / 2; p.dW = slabs + L.wv1(); p.db = slabs + L.bv1();
-      p.dvq = nullptr; p.s2 = a.dz; p.R = a.stash_v2; p.dvr = slabs + L.wv2();
-      if ((rc = dispatch_wgrad_p(p, stream))) return rc;
+      if (do_tail) {
+        // variance head layer 0 (+ predict weight: dw_p[j] = sum du * h_last[j])
+        p.P = (const char*)a.dpre_v1; p.Q = (const char*)a.stash_h + (nh - 1) * hb; p.OUT = H / 2; p.IN = H; p.dW = slabs + L.wv0(); p.db = slabs + L.bv0();
+        p.dvq = slabs + L.wp();
+        if ((rc = dispatch_wgrad_p(p, (void*)pick()))) return rc;
+        // variance head layer 1 (+ final weight: dwv2[i] = sum dz * v2[i], fp32 operands)
+        p.P = (const char*)a.dpre_v2; p.Q = (const char*)a.stash_v1; p.OUT = H / 4; p.IN = H / 2; p.dW = slabs + L.wv1(); p.db = slabs + L.bv1();
+        p.dvq = nullptr; p.s2 = a.dz; p.R = a.stash_v2; p.dvr = slabs + L.wv2();
+        if ((rc = dispatch_wgrad_p(p, (void*)pick()))) return rc;
+      }
     } else {
     const int ns = net->precision == PINN_PREC_F32X6 ? 4 : (net->precision == PINN_PREC_F32X6_G6 ? 3 : (net->precision == PINN_PREC_BF16 ? 1 : 0));
-    auto wgrad = [&](const WgradArgs& wa) { return ns ? dispatch_wgrad_x6(wa, ns, stream) : dispatch_wgrad(wa, st); };
-    for (int l = 1; l < nh; ++l) {
+    auto wgrad = [&](const WgradArgs& wa) { hipStream_t s_ = pick(); return ns ? dispatch_wgrad_x6(wa, ns, (void*)s_) : dispatch_wgrad(wa, s_); };
+    for (int l = nh - 1; l >= 1; --l) {
+      if (!in_part(l)) continue;
       g.P = a.dpre_h + l * hs; g.Q = a.stash_h + (l - 1) * hs; g.OUT = H; g.IN = H; g.dW = slabs + L.w(l); g.db = slabs + L.b(l);
       if ((rc = wgrad(g))) return rc;
     }
-    // variance head layer 0 (+ predict weight: dw_p[j] = sum du * h_last[j])
-    g.P = a.dpre_v1; g.Q = a.stash_h + (nh - 1) * hs; g.OUT = H / 2; g.IN = H; g.dW = slabs + L.wv0(); g.db = slabs + L.bv0();
-    g.s1 = a.du; g.dvq = slabs + L.wp();
-    if ((rc = wgrad(g))) return rc;
-    // variance head layer 1 (+ final weight: dwv2[i] = sum dz * v2[i])
-    g.P = a.dpre_v2; g.Q = a.stash_v1; g.OUT = H / 4; g.IN = H / 2; g.dW = slabs + L.wv1(); g.db = slabs + L.bv1();
-    g.s1 = nullptr; g.dvq = nullptr; g.s2 = a.dz; g.R = a.stash_v2; g.dvr = slabs + L.wv2();
-    if ((rc = wgrad(g))) return rc;
+    if (do_tail) {
+      // variance head layer 0 (+ predict weight: dw_p[j] = sum du * h_last[j])
+      g.P = a.dpre_v1; g.Q = a.stash_h + (nh - 1) * hs; g.OUT = H / 2; g.IN = H; g.dW = slabs + L.wv0(); g.db = slabs + L.bv0();
+      g.s1 = a.du; g.dvq = slabs + L.wp();
+      if ((rc = wgrad(g))) return rc;
+      // variance head layer 1 (+ final weight: dwv2[i] = sum dz * v2[i])
+      g.P = a.dpre_v2; g.Q = a.stash_v1; g.OUT = H / 4; g.IN = H / 2; g.dW = slabs + L.wv1(); g.db = slabs + L.bv1();
+      g.s1 = nullptr; g.dvq = nullptr; g.s2 = a.dz; g.R = a.stash_v2; g.dvr = slabs + L.wv2();
+      if ((rc = wgrad(g))) return rc;
     }
+    }
+    for (int k = 0; k < 3; ++k)
+      if (used[k]) { (void)hipEventRecord(g_fan.join[k], g_fan.side[k]); (void)hipStreamWaitEvent(st, g_fan.join[k], 0); }
   }
 
-  if (phases & PINN_PHASE_REDUCE) {
+  if (phases & (PINN_PHASE_REDUCE_TAIL | PINN_PHASE_REDUCE_HEAD)) {
     // (the gradient word of the range record sits behind the pack kernel's words: pack_x6_kernel cleared it for this call)
     unsigned* rw = net->precision == PINN_PREC_F32X6 ? range_status_words(net) : nullptr;
     if (rw) rw += kRangePackBlocks * (2 * (nh - 1) + 4);
-    hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((tot / 4 + kFinGroups - 1) / kFinGroups)), dim3(256), 0, st, slabs, w.n_slices, tot,
-                       a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss, (const unsigned*)(base + w.off_amax), rw);
+    const bool both = (phases & PINN_PHASE_REDUCE_TAIL) && (phases & PINN_PHASE_REDUCE_HEAD);
+    auto reduce = [&](long long lo, long long hi, int with_loss) {
+      hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)(((hi - lo) / 4 + kFinGroups - 1) / kFinGroups)), dim3(256), 0, st, slabs, w.n_slices, tot,
+                         a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss, (const unsigned*)(base + w.off_amax), rw, a.drop.step_counter, lo, hi,
+                         with_loss);
+    };
+    if (both) reduce(0, tot, 1);                               // one launch over the whole vector
+    else if (phases & PINN_PHASE_REDUCE_TAIL) reduce(split, tot, 1);
+    else if (split > 0) reduce(0, split, 0);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;

@@ -6,6 +6,18 @@
 namespace pinn {
 namespace x6 {
 
+#ifdef PINN_CLOCK_STAMP
+// diagnostic build only (tools/clock_in_kernel.py; MI355X_MICROARCH.md "DVFS give-back" item 6): s_memtime (shader cycles) and
+// s_memrealtime (100 MHz) of every workgroup at the start and the end of mlp_x6_kernel -> in-kernel clock.  The values go to a
+// buffer nothing else reads.
+__device__ unsigned long long g_clock_stamps[1024][4];
+__device__ __forceinline__ void clock_stamp(int slot) {
+  unsigned long long c, r;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r) :: "memory");
+  if (threadIdx.x == 0 && blockIdx.x < 1024) { g_clock_stamps[blockIdx.x][slot] = c; g_clock_stamps[blockIdx.x][slot + 1] = r; }
+}
+#endif
+
 struct PackJobs6 {
   PackJob j[18];
   int n;
@@ -110,6 +122,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp_x6_kernel(FwdArgs a
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long n_tiles = (a.n_rows + kTileRowsX - 1) / kTileRowsX;
+#ifdef PINN_CLOCK_STAMP
+  clock_stamp(0);
+#endif
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long lrow = tile * kTileRowsX + wave * kWaveRows + (lane & 15);
     const bool valid = lrow < a.n_rows;
@@ -155,6 +170,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp_x6_kernel(FwdArgs a
   if (blockIdx.x == 0 && lane == 0)
     for (int k = 0; k < 8; ++k) g_x6_stamps[wave * 8 + k] = pipe.seg[k];
 #endif
+#ifdef PINN_CLOCK_STAMP
+  clock_stamp(2);
+#endif
 }
 
 }  // namespace x6
@@ -195,6 +213,11 @@ int launch_forward_x6(const pinn_net_t* net, const FwdArgs& a, bool mc, void* st
 
 }  // namespace pinn
 
+#ifdef PINN_CLOCK_STAMP
+extern "C" int pinn_clock_debug_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pinn::x6::g_clock_stamps), sizeof(unsigned long long) * 1024 * 4);
+}
+#endif
 #ifdef PINN_X6_STAMP
 extern "C" int pinn_x6_debug_read(unsigned long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(pinn::x6::g_x6_stamps), sizeof(unsigned long long) * 64);

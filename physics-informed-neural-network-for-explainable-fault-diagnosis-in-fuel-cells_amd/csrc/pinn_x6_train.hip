@@ -54,6 +54,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_fwd_x3_kernel(Tra
   if (blockIdx.x == 0 && threadIdx.x == 0) *a.b.amax = 0u;      // the backward kernel (next in the stream) takes its atomicMax from 0
 
   const long long n_tiles = (a.n_rows + 127) / 128 * (128 / kTileRowsX);      // whole 128-row stash tiles
+  const unsigned pass0 = train_pass(a.drop);      // 0, or the device's step counter (replayed graphs)
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long t16 = tile * WAVES + wave;
     const long long lrow = t16 * 16 + (lane & 15);
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_fwd_x3_kernel(Tra
     const f32x4 xa = reinterpret_cast<const f32x4*>(a.x)[srow * 2];
     const f32x4 xb = reinterpret_cast<const f32x4*>(a.x)[srow * 2 + 1];
     const float yv = a.y[srow];
-    const RowCtx c{lane, kq, a.drop.row_offset + lrow, srow, a.n_rows, 0u, a.drop.mode};
+    const RowCtx c{lane, kq, a.drop.row_offset + lrow, srow, a.n_rows, pass0, a.drop.mode};
     const StashX sx{(float*)a.b.stash_h, (float*)a.b.stash_v1, (float*)a.b.stash_v2, (float*)a.b.dpre_h, (float*)a.b.dpre_v1, (float*)a.b.dpre_v2,
                     a.b.t16, t16};
 

@@ -522,28 +522,31 @@ __device__ __forceinline__ float dot8(const u32x4& v, const u32x4& w, float acc)
   return acc;
 }
 
-// A wave issues everything itself (one wave per SIMD: 256 accumulator registers), and an LDS-DMA instruction holds its issue
-// for 60-180 cycles: 17 of them in a burst at the top of a tile cost as much as the tile's 48 MFMAs (the first packed
-// version: 0.49 ms per 256 x 256 layer at 1e6 rows, against 0.54 split in registers -- the VALU work was gone, the burst
-// was not).  So the tile is cut into its TI x TJ blocks of three MFMAs and every block carries one DMA piece of tile t + 2
-// and, in the second half, its share of tile t + 1's transposing reads, pinned with sched_barrier: the pieces issue under
-// the matrix pipe's 96 cycles per block.
-template <int TI, int TJ, int WI, int WJ, bool kVQ, bool kVR>
-__global__ __launch_bounds__(256, 1) void wgrad_p_kernel(WgradPArgs a) {
-  constexpr int kFrags = TI + TJ, kBlocks = kFrags + (kVR ? TI : 0);      // 2-KB blocks per wave and tile: P, Q groups (+ R, fp32)
-  constexpr int kMetaAt = kBlocks * 2048, kStage = kMetaAt + 256;         // + the tile's row record
-  constexpr int kOps = 2 * kBlocks + 1;                                   // DMA instructions per tile
+// Schedule.  One wave per SIMD (256 accumulator registers), so a wave issues everything itself, and an LDS-DMA instruction holds
+// its issue for 60-180 cycles: the first packed version fetched into private rings in a burst at the top of a tile and took
+// 0.49 ms per 256 x 256 layer at 1e6 rows against 0.54 split in registers -- the VALU work was gone, the burst was not.
+// Ablations of the next version (pieces spread under the MFMAs; whole weight-gradient phase 1.75 ms): without the MFMAs
+// 1.72 -- the matrix work is hidden entirely --, without the DMA 1.11, non-temporal loads 2.0: the kernel is bound by its
+// memory path, and private rings fetch every P block for both waves of a wave row (every Q block for both of a column):
+// twice the DMA instructions and the second copy from L2 at best.  So the ring is SHARED: the workgroup's P, Q (and R) blocks
+// of a tile form one stage, every wave fetches a quarter of its 1-KB pieces, one barrier per tile publishes it.  The tile is
+// cut into its TI x TJ blocks of three MFMAs; every block carries its share of tile t + S's pieces and, in the second half,
+// of tile t + 1's transposing reads, pinned with sched_barrier.
+template <int TI, int TJ, int WI, int WJ, bool kVQ, bool kVR, int S>
+__global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_p_kernel(WgradPArgs a) {
+  constexpr int nW = WI * WJ, GP = TI * WI, GQ = TJ * WJ, GR = kVR ? GP : 0;      // the workgroup's blocks of a tile: P, Q, R groups
+  constexpr int kBlocks = GP + GQ + GR, kData = 2 * kBlocks;                      // 2-KB blocks, 1-KB data pieces per tile
+  constexpr int kMetaAt = kBlocks * 2048, kStage = kMetaAt + 256;                 // + the tile's row record
+  constexpr int kMine = (kData + nW - 1) / nW, kW = kMine + 1;                    // DMA instructions per wave and tile (+ the record, by every wave)
+  constexpr int kFrags = TI + TJ;                                                 // fragments a wave reads
   constexpr int NB = TI * TJ, kHalf = NB / 2;
-  constexpr int kPer = (kOps + NB - 1) / NB, kRd = (4 * kFrags + (NB - kHalf) - 1) / (NB - kHalf);
-  constexpr int kIssued = (kHalf + 1) * kPer < kOps ? (kHalf + 1) * kPer : kOps;      // this tile's pieces issued when the reads of the next start
-  extern __shared__ __attribute__((aligned(1024))) char ring_all[];
+  constexpr int kPer = (kW + NB - 1) / NB, kRd = (4 * kFrags + (NB - kHalf) - 1) / (NB - kHalf);
+  extern __shared__ __attribute__((aligned(1024))) char ring[];                   // S stages
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave >= WI * WJ) return;
-  char* ring = ring_all + wave * 2 * kStage;
   const int wi = wave / WJ, wj = wave % WJ;
   const int hh = lane >> 5, i = lane & 31;
-  const int gi0 = blockIdx.y * (TI * WI) + wi * TI, gj0 = blockIdx.z * (TJ * WJ) + wj * TJ;      // first 32-feature group of P / of Q
-  const int i0 = 32 * gi0, j0 = 32 * gj0;
+  const int gi0 = blockIdx.y * GP, gj0 = blockIdx.z * GQ;                         // the workgroup's first 32-feature group of P / of Q
+  const int i0 = 32 * (gi0 + wi * TI), j0 = 32 * (gj0 + wj * TJ);                 // this wave's first output row / column
   const bool row_sums = wj == 0 && blockIdx.z == 0, col_sums = wi == 0 && blockIdx.y == 0;
   const bool want_q = kVQ && col_sums && a.dvq;
   const int gP = a.OUT / 32, gQ = a.IN / 32;
@@ -568,21 +571,28 @@ __global__ __launch_bounds__(256, 1) void wgrad_p_kernel(WgradPArgs a) {
   long long t_end = t_begin + per;
   if (t_end > a.t16) t_end = a.t16;
 
-  // piece k of tile t: the hi (k even) or lo (k odd) KB of block k / 2 as it lies in memory (lane-linear 16 B per lane), the
-  // last one the tile's 256-B row record
-  struct Src { const char* p; const char* q; const char* r; const char* m; };
-  auto src_of = [&](long long t) {
-    return Src{a.P + ((t * gP + gi0) * 2048 + lane * 16), a.Q + ((t * gQ + gj0) * 2048 + lane * 16),
-               kVR ? (const char*)a.R + ((t * a.OUT + i0) * 64 + lane * 16) : nullptr, (const char*)a.meta + t * 256 + lane * 4};
-  };
-  auto piece = [&](const Src& s, char* st, auto kc) {
-    constexpr int k = decltype(kc)::value;
-    if constexpr (k < 2 * kBlocks) {
-      constexpr int f = k / 2, half = k % 2;
-      const char* base = f < TI ? s.p + f * 2048 : (f < kFrags ? s.q + (f - TI) * 2048 : s.r + (f - kFrags) * 2048);
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + half * 1024), (lptr_t)(st + f * 2048 + half * 1024), 16, 0, PINN_WG_AUX);
+  // this wave's j-th piece of tile t: piece p = wave + nW j of the tile's kData (wrapping: a wave with one piece fewer fetches
+  // an earlier one again -- same bytes to the same place); the last instruction of every wave is the tile's 256-B row record.
+  // Source (tile 0), bytes per tile and LDS offset of every piece are settled here, once: scalar registers, no branch in the loop.
+  const char* p_src[kMine];
+  long long p_step[kMine];
+  int p_dst[kMine];
+#pragma unroll
+  for (int j = 0; j < kMine; ++j) {
+    int p = wave + nW * j;
+    p = p < kData ? p : p - kData;
+    const int f = p >> 1, half = p & 1;
+    const bool isP = f < GP, isQ = !isP && f < GP + GQ;
+    p_src[j] = (isP ? a.P + (long long)(gi0 + f) * 2048 : (isQ ? a.Q + (long long)(gj0 + f - GP) * 2048 : (const char*)a.R + (long long)(gi0 + f - GP - GQ) * 2048)) + half * 1024;
+    p_step[j] = isP ? (long long)gP * 2048 : (isQ ? (long long)gQ * 2048 : (long long)a.OUT * 64);
+    p_dst[j] = f * 2048 + half * 1024;
+  }
+  auto piece = [&](long long t, char* st, auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < kMine) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(p_src[j] + t * p_step[j] + lane * 16), (lptr_t)(st + p_dst[j]), 16, 0, PINN_WG_AUX);
     } else {
-      __builtin_amdgcn_global_load_lds((gptr_t)s.m, (lptr_t)(st + kMetaAt), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)((const char*)a.meta + t * 256 + lane * 4), (lptr_t)(st + kMetaAt), 4, 0, 0);
     }
   };
   struct Regs {
@@ -590,13 +600,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_p_kernel(WgradPArgs a) {
     u32x4 tq, dh[kVQ ? 1 : 0], dl[kVQ ? 1 : 0];     // rows 8 hh .. 8 hh + 7: scales t_r; (kVQ) du_r norm_r as two fp16 parts
     f32x4 rr[kVR ? TI : 0][2], s2[kVR ? 2 : 0];     // (kVR) fp32 operands of the vector-head sum: R rows, dz
   };
-  // transposing reads: lane 4 q' + p' of a 16-lane group addresses (row q' of the 4-row block, 8-byte piece p'); one base
-  // register, everything else in the instruction's offset field
+  // transposing reads: lane 4 q' + p' of a 16-lane group addresses (row q' of the 4-row block, 8-byte piece p'); this wave's P
+  // fragments start at block wi TI of a stage, its Q fragments at block GP + wj TJ: two base registers, the rest immediates
   const int L = lane & 15;
   const unsigned lane_off = (unsigned)((8 * hh + (L >> 2)) * 64 + (2 * ((lane >> 4) & 1) + ((L & 3) >> 1)) * 16 + (L & 1) * 8);
-  auto read_one = [&](Regs& r, unsigned base, auto jc) {
+  const unsigned off_p = lane_off + (unsigned)(wi * TI) * 2048u, off_q = lane_off + (unsigned)(GP + wj * TJ) * 2048u;
+  auto read_one = [&](Regs& r, unsigned stage_addr, auto jc) {
     constexpr int j = decltype(jc)::value, f = j / 4, sub = j % 4;
-    r.w[f][sub] = lds_read_tr16<f * 2048 + (sub >> 1) * 1024 + (sub & 1) * 256>(base);
+    constexpr int fl = f < TI ? f : f - TI;
+    r.w[f][sub] = lds_read_tr16<fl * 2048 + (sub >> 1) * 1024 + (sub & 1) * 256>(stage_addr + (f < TI ? off_p : off_q));
   };
   auto read_side = [&](Regs& r, const char* st) {
     const char* m = st + kMetaAt + 16 * hh;
@@ -610,36 +622,40 @@ __global__ __launch_bounds__(256, 1) void wgrad_p_kernel(WgradPArgs a) {
       r.s2[1] = *reinterpret_cast<const f32x4*>(st + kMetaAt + 128 + 32 * hh + 16);
 #pragma unroll
       for (int ti = 0; ti < TI; ++ti) {
-        r.rr[ti][0] = *reinterpret_cast<const f32x4*>(st + (kFrags + ti) * 2048 + i * 64 + 32 * hh);
-        r.rr[ti][1] = *reinterpret_cast<const f32x4*>(st + (kFrags + ti) * 2048 + i * 64 + 32 * hh + 16);
+        r.rr[ti][0] = *reinterpret_cast<const f32x4*>(st + (GP + GQ + wi * TI + ti) * 2048 + i * 64 + 32 * hh);
+        r.rr[ti][1] = *reinterpret_cast<const f32x4*>(st + (GP + GQ + wi * TI + ti) * 2048 + i * 64 + 32 * hh + 16);
       }
     }
   };
   auto frag_hi = [](const Regs& r, int f) { return u32x4{r.w[f][0][0], r.w[f][0][1], r.w[f][1][0], r.w[f][1][1]}; };
   auto frag_lo = [](const Regs& r, int f) { return u32x4{r.w[f][2][0], r.w[f][2][1], r.w[f][3][0], r.w[f][3][1]}; };
+  auto stage_addr = [&](const char* st) { return (unsigned)(unsigned long long)(lptr_t)st; };
 
   if (t_begin < t_end) {
     auto clampt = [&](long long t) { return t < t_end ? t : t_end - 1; };
     Regs cur, nxt;
-    {
-      const Src s0 = src_of(t_begin), s1 = src_of(clampt(t_begin + 1));
-      static_for<kOps>([&](auto kc) { piece(s0, ring, kc); });
-      static_for<kOps>([&](auto kc) { piece(s1, ring + kStage, kc); });
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps) : "memory");       // tile t_begin has landed
-      const unsigned base = (unsigned)(unsigned long long)(lptr_t)ring + lane_off;
-      static_for<4 * kFrags>([&](auto jc) { read_one(cur, base, jc); });
-      read_side(cur, ring);
-    }
+    // S tiles in flight; the first one into registers
+#pragma unroll
+    for (int s = 0; s < S; ++s) static_for<kW>([&](auto jc) { piece(clampt(t_begin + s), ring + s * kStage, jc); });
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * kW) : "memory");       // this wave's pieces of tile t_begin have landed ...
+    __builtin_amdgcn_s_barrier();                                              // ... and so have the other waves'
+    asm volatile("" ::: "memory");
+    static_for<4 * kFrags>([&](auto jc) { read_one(cur, stage_addr(ring), jc); });
+    read_side(cur, ring);
+    int s_cur = 0;                     // stage of tile t
     for (long long t = t_begin; t < t_end; ++t) {
-      const int s0 = (int)((t - t_begin) & 1);
-      // stage s0 (tile t) is in registers: it takes tile t + 2, piece by piece under the MFMAs; the other stage (tile t + 1)
-      // has landed once all but this tile's own pieces are through
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // ... the LDS reads of `cur` are done
+      const int s_next = s_cur + 1 == S ? 0 : s_cur + 1;
+      // `cur` (tile t, read from stage s_cur) is complete; this wave's pieces of tile t + 1 have landed.  Past the barrier that
+      // holds for every wave: stage s_next can be read, stage s_cur refilled with tile t + S.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * kW) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      const Src sn = src_of(clampt(t + 2));
-      char* st_fill = ring + s0 * kStage;
-      const char* st_next = ring + (s0 ^ 1) * kStage;
-      const unsigned base_next = (unsigned)(unsigned long long)(lptr_t)st_next + lane_off;
+      const long long t_fill = clampt(t + S);
+      char* st_fill = ring + s_cur * kStage;
+      const char* st_next = ring + s_next * kStage;
+      const unsigned a_next = stage_addr(st_next);
       u32x4 qh[TJ], ql[TJ];
       static_for<NB>([&](auto bc) {
         constexpr int b = decltype(bc)::value, ti = b / TJ, tj = b % TJ;
@@ -658,20 +674,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_p_kernel(WgradPArgs a) {
 #ifndef PINN_ABL_WGP_NODMA
         static_for<kPer>([&](auto ic) {
           constexpr int k = b * kPer + decltype(ic)::value;
-          if constexpr (k < kOps) piece(sn, st_fill, IC<k>{});
+          if constexpr (k < kW) piece(t_fill, st_fill, IC<k>{});
         });
 #endif
-        if constexpr (b == kHalf) {
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kIssued) : "memory");
 #ifndef PINN_ABL_WGP_NOREAD
-          read_side(nxt, st_next);
-#endif
-        }
-#ifndef PINN_ABL_WGP_NOREAD
+        if constexpr (b == kHalf) read_side(nxt, st_next);
         if constexpr (b >= kHalf) {
           static_for<kRd>([&](auto ic) {
             constexpr int j = (b - kHalf) * kRd + decltype(ic)::value;
-            if constexpr (j < 4 * kFrags) read_one(nxt, base_next, IC<j>{});
+            if constexpr (j < 4 * kFrags) read_one(nxt, a_next, IC<j>{});
           });
         }
 #endif
@@ -701,6 +712,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_p_kernel(WgradPArgs a) {
 #ifndef PINN_ABL_WGP_NOREAD
       cur = nxt;
 #endif
+      s_cur = s_next;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing re-fetches must land before the LDS is released
   }
@@ -747,14 +759,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_p_kernel(WgradPArgs a) {
 
 template <int TI, int TJ, int WI, int WJ, bool kVQ = false, bool kVR = false>
 static int launch_p(const WgradPArgs& a, hipStream_t st) {
+  constexpr int kBlocks = TI * WI + TJ * WJ + (kVR ? TI * WI : 0), kStage = kBlocks * 2048 + 256;
+  constexpr int S = 4 * kStage <= 140 * 1024 ? 4 : 3;      // stages the 160-KB LDS holds (three tiles ahead where four fit)
   const dim3 grid(a.n_slices, a.OUT / (TI * 32 * WI), a.IN / (TJ * 32 * WJ));
-  const size_t lds = (size_t)WI * WJ * 2 * ((TI + TJ + (kVR ? TI : 0)) * 2048 + 256);
-  auto k = wgrad_p_kernel<TI, TJ, WI, WJ, kVQ, kVR>;
+  const size_t lds = (size_t)S * kStage;
+  auto k = wgrad_p_kernel<TI, TJ, WI, WJ, kVQ, kVR, S>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k, grid, dim3(64 * WI * WJ), lds, st, a);
   return PINN_OK;
 }
 

@@ -57,6 +57,14 @@ def allreduce_grads(grad_full, group=None, force=False):
     return allreduce_bucket(grad_full, group, force)
 
 
+def allreduce_grads_begin(part, group=None, force=False):
+    """Start the SUM of one part of the gradient bucket and return its work handle (None for a single process): the two-part
+    step of model.train_dnn puts the tail's collective on a side stream under the head's weight-gradient kernels."""
+    if _active(group, force):
+        return dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return None
+
+
 def allreduce_sums(sums, group=None, force=False):
     """fp64 sums: the residual-pass sums (double[32]) of a physics-parameter stage, or the loss sums (double[4])."""
     if _active(group, force):

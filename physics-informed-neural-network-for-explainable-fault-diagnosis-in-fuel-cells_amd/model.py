@@ -353,9 +353,11 @@ class PhysicsInformedNN():
             self._work[key] = torch.empty(wb, dtype=torch.uint8, device=self.x.device)
         return self._work[key]
 
-    def train_step_grads(self, x, y, row_offset, n_global):
+    def train_step_grads(self, x, y, row_offset, n_global, between=None):
         """One fused forward + aleatoric_loss + backward on rows (x, y): fills the flat gradient
-        (already divided by n_global) and returns the raw loss sums double[4] on the device."""
+        (already divided by n_global) and returns the raw loss sums double[4] on the device.
+        `between` (data-parallel overlap): called once the TAIL of the gradient -- last hidden layer and heads,
+        [pinn_grad_split, end) -- is final, before the head's weight-gradient kernels are launched."""
         n = x.shape[0]
         work = self._workspace(n)
         self._step_counter += 1
@@ -364,10 +366,109 @@ class PhysicsInformedNN():
         if drop is not None and self.dnn._mask_bits is not None:
             self.dnn._mask_pass += 1
         loss = torch.empty(4, dtype=torch.float64, device=x.device)
-        rc = self._lib.pinn_mlp_train_grads(ctypes.byref(self.dnn._net), _ptr(self.dnn.flat_params()), _ptr(x), _ptr(y), n,
-                                            int(n_global), ctypes.byref(drop) if drop else None,
-                                            _ptr(self.dnn._flat_grad), _ptr(loss), _ptr(work), work.numel(), _stream())
-        _lib.check(rc, "pinn_mlp_train_grads")
+
+        def run(phases):
+            rc = self._lib.pinn_mlp_train_grads_phases(ctypes.byref(self.dnn._net), _ptr(self.dnn.flat_params()), _ptr(x), _ptr(y), n,
+                                                       int(n_global), ctypes.byref(drop) if drop else None,
+                                                       _ptr(self.dnn._flat_grad), _ptr(loss), _ptr(work), work.numel(), _stream(), phases)
+            _lib.check(rc, "pinn_mlp_train_grads")
+        if between is None:
+            run(_lib.PHASE_ALL)
+        else:
+            run(_lib.PHASE_CHAIN | _lib.PHASE_WGRAD_TAIL | _lib.PHASE_REDUCE_TAIL)
+            between()
+            run(_lib.PHASE_WGRAD_HEAD | _lib.PHASE_REDUCE_HEAD)
+        return loss
+
+    # Data-parallel step with the gradient all-reduce in two parts: the tail of the bucket (last hidden layer +
+    # heads, 0.43 of 0.70 MB for the reference net) is summed on a side stream while the head's weight-gradient kernels run;
+    # both parts are complete before Adam.  Two ranks sum the same pairs of floats either way: bit-identical to one blocking
+    # all-reduce (tests/test_gpu_dp.py); overlap_allreduce = False keeps the single collective.
+    overlap_allreduce = True
+
+    def _dp_step(self, xb, yb, row_offset, n_norm, has_rows):
+        full = self.dnn._flat_grad_full
+        split = int(self._lib.pinn_grad_split(ctypes.byref(self.dnn._net))) if self.overlap_allreduce else 0
+        if not (_dp._active(self._group) and split > 0):
+            if has_rows:
+                loss = self.train_step_grads(xb, yb, row_offset, n_norm)
+            else:       # a rank without rows in this batch: zero gradient, same dropout-stream position, same collective
+                self._step_counter += 1
+                full.zero_()
+                loss = torch.zeros(4, dtype=torch.float64, device=self.x.device)
+            _dp.allreduce_grads(full, self._group)
+            return loss
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.x.device)
+        works = []
+
+        def tail_ready():
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self._side_stream):
+                self._side_stream.wait_event(ev)
+                works.append(_dp.allreduce_grads_begin(full[split:], self._group))
+        if has_rows:
+            loss = self.train_step_grads(xb, yb, row_offset, n_norm, between=tail_ready)
+        else:
+            self._step_counter += 1
+            full.zero_()
+            loss = torch.zeros(4, dtype=torch.float64, device=self.x.device)
+            tail_ready()
+        works.append(_dp.allreduce_grads_begin(full[:split], self._group))
+        for w in works:
+            if w is not None:
+                w.wait()              # the current stream waits for the collective (NCCL); gloo: the host does
+        return loss
+
+    # train_dnn at the reference's data sizes (1e3-1e4 rows, 12 002 steps: 01:2143-2147) is launch-bound: ten dependent launches
+    # per step.  With one process and full batches the step is captured ONCE as a hipGraph and replayed: step count, Adam
+    # coefficients and dropout stream live on the device (pinn_dropout_t.d_step_counter, pinn_adam_step_dev), so nothing
+    # in the captured sequence changes from step to step.  Same kernels, same arguments otherwise: bit-identical to the
+    # launch-by-launch path (tests/test_gpu_model.py); use_graph = False forces that path.
+    use_graph = True
+
+    def _train_dnn_replay(self, epochs, x, y, n_norm, log):
+        """Steps 2 .. epochs of a full-batch train_dnn call as replays of one captured step (step 1 ran launch by launch:
+        it also settles every lazy launch attribute before the capture)."""
+        dev = x.device
+        n = x.shape[0]
+        flat, grad = self.dnn.flat_params(), self.dnn._flat_grad
+        coeffs = np.empty((epochs, 2), dtype=np.float32)
+        ss, bs = ctypes.c_float(), ctypes.c_float()
+        for k in range(epochs):             # entry k: optimizer step k + 1, lr of epoch k (StepLR(1000, 0.8), 01:939-940)
+            self._lib.pinn_adam_coeffs(ctypes.c_float(0.01 * 0.8 ** (k // 1000)), k + 1, ctypes.byref(ss), ctypes.byref(bs))
+            coeffs[k] = (ss.value, bs.value)
+        d_coeffs = torch.from_numpy(coeffs).to(dev)
+        counter = torch.ones(1, dtype=torch.int32, device=dev)          # one step done
+        work = self._workspace(n)
+        loss = torch.empty(4, dtype=torch.float64, device=dev)
+        training = self.dnn.training and any(m.p > 0 for m in self.dnn.dropout_modules())
+        # step k of the call draws stream S0 + k and mask pass M0 + k - 1 (S0, M0: the positions before the call, as train_step_grads
+        # counts them); the kernels add the device counter = k - 1 to what the struct holds
+        drop = self.dnn.dropout_struct(self._step_counter, self.row_offset, mode=None if training else _lib.DROP_NONE)
+        if training and self.dnn._mask_bits is not None:
+            drop.d_bits = self.dnn._mask_bits[self.dnn._mask_pass - 1].data_ptr()
+        drop.d_step_counter = counter.data_ptr()
+        net = self.dnn._net
+
+        def step():
+            _lib.check(self._lib.pinn_mlp_train_grads(ctypes.byref(net), _ptr(flat), _ptr(x), _ptr(y), n, int(n_norm), ctypes.byref(drop),
+                                                      _ptr(grad), _ptr(loss), _ptr(work), work.numel(), _stream()), "pinn_mlp_train_grads")
+            _lib.check(self._lib.pinn_adam_step_dev(_ptr(flat), _ptr(grad), _ptr(self._adam_m), _ptr(self._adam_v), flat.numel(),
+                                                    _ptr(d_coeffs), _ptr(counter), _stream()), "pinn_adam_step_dev")
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        for epoch in range(1, epochs):
+            graph.replay()
+            if epoch % 1000 == 0:
+                log(epoch, loss)
+        torch.cuda.current_stream().synchronize()
+        self._step_counter += epochs - 1
+        if training and self.dnn._mask_bits is not None:
+            self.dnn._mask_pass += epochs - 1
+        self._keep_alive = (d_coeffs, counter, work, loss, graph)      # until the next call: the stream may still be replaying
         return loss
 
     def train_dnn(self, nIter, batch_size=None):
@@ -389,26 +490,28 @@ class PhysicsInformedNN():
         n_norm = max(1, self.n_global)
         # the schedule has the same length on every rank (empty batches included): one gradient all-reduce per entry
         batches = _dp.batch_schedule(n, batch_size, self.x.device, self._group)
+
+        def log_line(epoch, sums):
+            self.dnn.check_range()
+            ls = _dp.allreduce_sums(sums.clone(), self._group).cpu().numpy()      # fp64, only when a line is printed
+            lr_next = 0.01 * 0.8 ** ((epoch + 1) // 1000)
+            self._log(f' {epoch:5d}  | {(ls[0] + 0.01 * ls[1]) / n_norm:10.3e} | {ls[2] / n_norm:10.3e} | {lr_next:8.1e}')
+        replay = (self.use_graph and nIter >= 2 and len(batches) == 1 and batches[0][:2] == (0, n) and n > 0 and not _dp._active(self._group)
+                  and self.dnn.hidden <= 256)
         for epoch in range(nIter):
             lr = 0.01 * 0.8 ** (epoch // 1000)
             for (s, e, n_norm) in batches:
-                if e > s:
-                    xb, yb = (x, y) if (s, e) == (0, n) else (x[s:e], y[s:e])
-                    loss_sums = self.train_step_grads(xb, yb, self.row_offset + s, n_norm)
-                else:       # a rank without rows in this batch: zero gradient, same dropout-stream position, same collective
-                    self._step_counter += 1
-                    self.dnn._flat_grad_full.zero_()
-                    loss_sums = torch.zeros(4, dtype=torch.float64, device=self.x.device)
-                _dp.allreduce_grads(self.dnn._flat_grad_full, self._group)
+                xb, yb = (x, y) if (s, e) == (0, n) else (x[s:e], y[s:e])
+                loss_sums = self._dp_step(xb, yb, self.row_offset + s, n_norm, e > s)
                 step += 1
                 rc = self._lib.pinn_adam_step(_ptr(flat), _ptr(grad), _ptr(self._adam_m), _ptr(self._adam_v), flat.numel(),
                                               lr, step, _stream())
                 _lib.check(rc, "pinn_adam_step")
             if epoch % 1000 == 0 and loss_sums is not None:
-                self.dnn.check_range()
-                ls = _dp.allreduce_sums(loss_sums.clone(), self._group).cpu().numpy()      # fp64, only when a line is printed
-                lr_next = 0.01 * 0.8 ** ((epoch + 1) // 1000)
-                self._log(f' {epoch:5d}  | {(ls[0] + 0.01 * ls[1]) / n_norm:10.3e} | {ls[2] / n_norm:10.3e} | {lr_next:8.1e}')
+                log_line(epoch, loss_sums)
+            if replay:
+                loss_sums = self._train_dnn_replay(nIter, x, y, n_norm, log_line)
+                break
         if loss_sums is not None:
             self.dnn.check_range()
             ls = _dp.allreduce_sums(loss_sums.clone(), self._group).cpu().numpy()

@@ -46,6 +46,7 @@ def dropout_struct(mode, p_list, seed=0, stream_id=0, row_offset=0, bits=None):
     d.stream = stream_id
     d.row_offset = row_offset
     d.d_bits = bits.data_ptr() if bits is not None else None
+    d.d_step_counter = None
     return d
 
 

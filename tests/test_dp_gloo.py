@@ -56,7 +56,15 @@ def _worker(rank, world, port, q):
     for step in (1, 2, 3):
         g, sums = _local_step(P, x, y, lo, hi, N, step)
         bucket = torch.cat([g, torch.zeros(dp.LOSS_TAIL)])
+        # the two-part form model.train_dnn overlaps with the head's weight-gradient kernels (tail of the bucket first, both
+        # started asynchronously, both waited for before Adam) against ONE blocking all-reduce: the same bits
+        two = bucket.clone()
+        split = sum(p.numel() for p in P[:2 * (NH - 1)])          # [W0 b0 .. W_{h-2} b_{h-2}] | last hidden layer, heads
+        works = [dp.allreduce_grads_begin(two[split:], None), dp.allreduce_grads_begin(two[:split], None)]
+        for w in works:
+            w.wait()
         dp.allreduce_grads(bucket, None)
+        assert torch.equal(two, bucket), "two-part all-reduce differs from the single one"
         dp.allreduce_sums(sums, None)
         g = bucket[:-dp.LOSS_TAIL]
         grads, k = [], 0

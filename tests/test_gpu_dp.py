@@ -114,7 +114,16 @@ def _dp_worker(rank, world, port, q):
         b = _state(m)
         _stages(m)
         c = _state(m)
-        q.put(("ok", rank, a, b, c, m.last_loss))
+        # the same two calls with ONE blocking all-reduce per step instead of the two-part overlapped one: bit for bit the same
+        m1 = _model(x[lo:hi], y[lo:hi], sx, sy, lo=lo, n_global=N)
+        m1.overlap_allreduce = False
+        m1.train_dnn(3)
+        a1 = _state(m1)
+        m1.train_dnn(2, batch_size=BATCH)
+        b1 = _state(m1)
+        same = bool(np.array_equal(a[0], a1[0]) and np.array_equal(b[0], b1[0]))
+        split = int(m._lib.pinn_grad_split(__import__("ctypes").byref(m.dnn._net)))
+        q.put(("ok", rank, a, b, c, m.last_loss, same, split))
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001
         q.put(("error", rank, repr(e)))
@@ -186,3 +195,5 @@ def test_two_ranks_on_one_card_equal_single_process():
         assert (err > tol).mean() <= 1e-4 and err.max() <= 2e-3, "weights, stage %d: %d outliers, max %.3g" % (stage, (err > tol).sum(), err.max())
         np.testing.assert_allclose(r0[1], want[1], rtol=5e-4, atol=1e-7, err_msg="physics parameters, stage %d" % stage)
     assert np.isfinite(outs[0][5]) and outs[0][5] == outs[1][5]
+    # the overlapped two-part all-reduce (tail under the head's weight-gradient kernels) against the single blocking one
+    assert outs[0][7] > 0 and all(o[6] for o in outs), "two-part all-reduce differs from the blocking one"

@@ -325,6 +325,38 @@ def test_train_dnn_philox_masks_vs_oracle(batch_size):
         assert np.abs(dev - r32).max() <= 2e-3, (n, float(np.abs(dev - r32).max()))      # sanity: the steps happened (lr = 0.01)
 
 
+@pytest.mark.parametrize("precision,H", [("f32x6", 256), ("f32x6", 128), ("fp32", 128), ("bf16", 256), ("f32x6g6", 128)])
+def test_train_dnn_graph_replay_is_bit_identical(precision, H):
+    """SURVEY 8(f) F1 / 01:939-955: a full-batch train_dnn call replays ONE captured step (hipGraph; step count, Adam
+    coefficients and dropout stream on the device) -- and must leave exactly the weights, Adam moments, loss and
+    dropout-stream position that the launch-by-launch path leaves, with on-chip Philox masks and with injected ones
+    (the golden three-step test and the float64-referee trajectory test above run through the replay path as well)."""
+    import hip_helpers as hh
+    import pinn_amd
+    from pinn_amd import synth
+    N, steps = 700, 9
+    ds = synth.make_dataset(N, (), seed=21)
+
+    def run(use_graph, bits):
+        torch.manual_seed(5)
+        m = pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, H, H, H, 1], ds[4], ds[5], p=0.2, logvar=True, seed=31, precision=precision)
+        m.verbose = False
+        m.use_graph = use_graph
+        if bits is not None:
+            m.dnn.inject_masks(bits)
+        m.train_dnn(steps)
+        a = (m.dnn.flat_params().clone(), m._adam_m.clone(), m._adam_v.clone(), m.last_loss, m._step_counter, m.dnn._mask_pass)
+        m.train_dnn(3)                     # a second call continues the stream where the first one left it
+        return a + (m.dnn.flat_params().clone(),)
+    g = torch.Generator().manual_seed(9)
+    per_pass = [[(torch.rand(N, w, generator=g) >= 0.2).numpy() for w in (H, H, H, H // 2)] for _ in range(steps + 3)]
+    for bits in (None, hh.pack_mask_bits(per_pass)):
+        eager, graph = run(False, bits), run(True, bits)
+        for k, (a, b) in enumerate(zip(eager, graph)):
+            assert (torch.equal(a, b) if torch.is_tensor(a) else a == b), ("element %d differs" % k, precision, bits is not None)
+        assert torch.isfinite(eager[0]).all() and eager[4] == steps
+
+
 def test_reference_main_flow(tmp_path):
     """The reference's `__main__` (01:2055-2201) end to end on synthetic recordings: ingest -> seven trainer calls -> results
     array -> .mat as scripts 02-05 read it (02:105-114), at 0.2 % of the schedule."""

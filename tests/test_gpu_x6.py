@@ -1,6 +1,7 @@
-"""GPU parity of the fp32-accurate matrix-core kernels (pinn_net_t.precision = PINN_PREC_F32X6):
-3-way bf16 split of both operands, six bf16 MFMAs per product, fp32 accumulation.  The bar is the
-SAME fp32 tolerance as the exact-fp32 kernels (rtol = atol = 1e-5 against the fp32 oracle)."""
+"""GPU parity of the fp32-accurate matrix-core kernels: pinn_net_t.precision = PINN_PREC_F32X6 (every product from two fp16
+parts per operand, three MFMAs, fp32 accumulation; packed fp16 training stash) and PINN_PREC_F32X6_G6 (gradients from three
+bf16 parts, six MFMAs), fused and wide nets.  The bar is the SAME fp32 tolerance as the exact-fp32 kernels (rtol = atol =
+1e-5 against the fp32 oracle), plus float64 referees for the gradients and the range / NaN behaviour at the domain's edge."""
 import ctypes
 
 import numpy as np
