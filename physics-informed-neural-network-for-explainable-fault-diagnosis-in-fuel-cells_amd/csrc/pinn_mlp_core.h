@@ -503,6 +503,7 @@ struct TrainBuffers {
   unsigned* emax;     // bits of max over rows of max(|du|, |dz|): the forward kernel's atomicMax, zeroed by the pack kernel before it
   void* rowmeta;      // [t16][256 B]: per tile the rows' scales t_r, the two fp16 parts of du_r * norm_r, dz_r (struct RowMeta)
   int qboost;         // c of t_r = 2^(e_r - E + c): the headroom 8 |h| <= 8 / (1 - p) leaves in fp16
+  void* stash_x;      // [t16][2 KB]: the input rows as one packed 32-feature group (8 real features, x / 16): layer 0's weight gradient
 };
 
 // kernel arguments of the forward / MC-dropout kernels (fp32 and bf16 variants)

@@ -513,7 +513,7 @@ static FanOut g_fan;
 struct Workspace {
   long long t16;
   size_t off_stash_h, off_stash_v1, off_stash_v2, off_dpre_h, off_dpre_v1, off_dpre_v2, off_keep, off_du, off_dz, off_loss,
-      off_amax, off_rowmeta, off_slabs;
+      off_amax, off_rowmeta, off_stash_x, off_slabs;
   int n_slices;
   size_t total;
 };
@@ -537,6 +537,7 @@ static Workspace plan_workspace(const pinn_net_t* net, long long n_rows) {
   w.off_loss = take((size_t)1024 * kLossTerms * 8);
   w.off_amax = take(256);                                   // [0] TrainBuffers::amax, [1] ::emax
   w.off_rowmeta = take((size_t)w.t16 * 256);                // struct RowMeta records
+  w.off_stash_x = take((size_t)w.t16 * 2048);               // packed input rows (PINN_PREC_F32X6, fused nets)
   const long long t32 = (w.t16 + 1) / 2;
   // slices = workgroups per weight-gradient launch = slabs the reduction adds.  Large row counts: one per CU.  The reference's
   // own sizes (< 32 768 rows) are bound by the slabs instead -- at 1e4 rows 256 slices wrote 67 MB per 256 x 256 layer and the
@@ -723,7 +724,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
       b.keep = a.keep; b.du = a.du; b.dz = a.dz; b.loss_part = a.loss_part;
       b.slabs = (float*)(base + w.off_slabs); b.t16 = w.t16; b.n_slices = w.n_slices;
       b.amax = (unsigned*)(base + w.off_amax);
-      b.emax = b.amax + 1; b.rowmeta = base + w.off_rowmeta; b.qboost = row_scale_boost(a.drop, nh);
+      b.emax = b.amax + 1; b.rowmeta = base + w.off_rowmeta; b.qboost = row_scale_boost(a.drop, nh); b.stash_x = base + w.off_stash_x;
       rc = H > 256 ? launch_train_chain_wide(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, &grid, stream)
                    : launch_train_chain_x6(net, d_params, d_x, d_y, n_rows, n_global, a.drop, b, which, &grid, stream);
       if (rc) return rc;
@@ -770,7 +771,8 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     // layer 0: dW0 = dpre_0 x^T
     g.P = a.dpre_h; g.Q = nullptr; g.OUT = H; g.IN = 8; g.dW = slabs + L.w0(); g.db = slabs + L.b0();
     g.s1 = nullptr; g.dvq = nullptr; g.s2 = nullptr; g.R = nullptr; g.dvr = nullptr;
-    if (do_head) { if ((rc = dispatch_wgrad(g, pick()))) return rc; }
+    const bool packed0 = net->precision == PINN_PREC_F32X6 && H <= 256;       // layer 0 from the packed operands too (below)
+    if (do_head && !packed0) { if ((rc = dispatch_wgrad(g, pick()))) return rc; }
     // every layer but the input one: split-bf16 products on the matrix cores for PINN_PREC_F32X6
     // operand split of the weight-gradient kernels: 0 = exact fp32 kernels; 3 = three bf16 parts, six products (x6); 4 = two fp16
     // parts under the common scale the X3 backward kernels measured (PINN_PREC_F32X6); 1 = bf16-mixed (wide nets)
@@ -778,8 +780,16 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
       // packed stash: the chain kernels left every operand as fp16 fragments (pinn_x6_core.h), the row scales in the meta records
       WgradPArgs p{};
       p.meta = base + w.off_rowmeta; p.emax = (const unsigned*)(base + w.off_amax) + 1; p.qboost = row_scale_boost(a.drop, nh);
-      p.t16 = w.t16; p.n_slices = w.n_slices; p.slab_stride = tot;
+      p.t16 = w.t16; p.n_slices = w.n_slices; p.slab_stride = tot; p.q_log2 = 3;
       const long long hb = hs * 4;      // bytes per hidden-layer stash
+      if (do_head) {
+        // layer 0: dW0 = d pre_0^T x with the rows as a packed group of their own (8 features of 32, stored as x / 16: any
+        // |x| < 256 survives the row scale in fp16); [H][8] of the [H][32] product is written
+        p.P = (const char*)a.dpre_h; p.Q = (const char*)(base + w.off_stash_x); p.OUT = H; p.IN = 32; p.dW = slabs + L.w0(); p.db = slabs + L.b0();
+        p.ldW = 8; p.n_cols = 8; p.q_log2 = -4;
+        if ((rc = dispatch_wgrad_p(p, (void*)pick()))) return rc;
+        p.ldW = 0; p.n_cols = 0; p.q_log2 = 3;
+      }
       for (int l = nh - 1; l >= 1; --l) {
         if (!in_part(l)) continue;
         p.P = (const char*)a.dpre_h + l * hb; p.Q = (const char*)a.stash_h + (l - 1) * hb; p.OUT = H; p.IN = H; p.dW = slabs + L.w(l); p.db = slabs + L.b(l);

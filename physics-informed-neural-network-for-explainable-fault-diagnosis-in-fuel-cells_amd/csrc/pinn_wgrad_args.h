@@ -27,6 +27,8 @@ struct WgradPArgs {
   const void* meta;  // [T16][256 B]: struct RowMeta records (row scales t_r, du_r norm_r as two fp16 parts, dz_r)
   const unsigned* emax;   // bits of the call's largest max(|du|, |dz|) -> E
   int qboost;             // c
+  int q_log2;             // log2 of the scale the Q stash carries: 3 (8 x the activation) or -4 (the input rows, x / 16)
+  int ldW, n_cols;        // 0, or (layer 0: IN = 32 of which 8 are real) the leading dimension of dW and the columns to write
   int OUT, IN;
   long long t16;
   int n_slices;

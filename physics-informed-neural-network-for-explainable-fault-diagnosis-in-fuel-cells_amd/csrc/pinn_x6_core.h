@@ -1015,21 +1015,19 @@ __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLa
     for (int t = 0; t < NT; ++t) dh[t] = acc[t];
   }
 
-  // ---- layer 0: d pre_0 = d h_0 * tanh' (no matrix follows: plain loads, all issued before the arithmetic); fp32, true
-  //      units in every scheme: its weight gradient (K = 8 inputs) is the exact-fp32 kernel's
+  // ---- layer 0: d pre_0 = d h_0 * tanh' (no matrix follows: plain loads, all issued before the arithmetic).  Packed like the
+  //      others in scheme X3 (its weight gradient reads the packed input rows, stash_x); fp32 in true units otherwise
   {
     const LayerDrop ld0 = layer_drop(d, mode, 0);
-    const float gscale = ld0.scale * kInvW * unnorm, inv_scale = kInvA / ld0.scale;       // straight to true units
-    float* dsp = sx.dact(0, H, lane);
+    const float gscale = ld0.scale * kInvW * (kPack ? 1.0f : unnorm), inv_scale = kInvA / ld0.scale;
     auto one = [&](float h, float dv) -> float {
       const float a0 = h * inv_scale;
       const float g0 = dv * (gscale * (1.0f - a0 * a0));
-      const float o = h != 0.0f ? g0 : 0.0f;
-      if constexpr (S::kActScale != 1.0f) amax = fmaxf(amax, fabsf(o));      // (already in true units)
-      return o;
+      return h != 0.0f ? g0 : 0.0f;
     };
     if constexpr (kPack) {
       const float* hp = sx.actp(0, H, lane);
+      float* dsp = sx.dactp(0, H, lane);
       StashFrag fr[NP];
 #pragma unroll
       for (int g = 0; g < NP; ++g) {
@@ -1038,23 +1036,29 @@ __device__ __forceinline__ void backward_pass(const float* smallp, const ParamLa
       }
       static_for<NP>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
+        Frag out;
         static_for<4>([&](auto rc) {
           constexpr int r = decltype(rc)::value;
-          dh[2 * g][r] = one(unpack_act<0, r>(fr[g]), dh[2 * g][r]);
-          dh[2 * g + 1][r] = one(unpack_act<1, r>(fr[g]), dh[2 * g + 1][r]);
+          const float p0 = one(unpack_act<0, r>(fr[g]), dh[2 * g][r]), p1 = one(unpack_act<1, r>(fr[g]), dh[2 * g + 1][r]);
+          mx = fmaxf(fmaxf(mx, fabsf(p0)), fabsf(p1));      // (normalised units)
+          S::template split<r>(p0, p1, out);
         });
-        store_block(dsp, 2 * g, dh[2 * g]);
-        store_block(dsp, 2 * g + 1, dh[2 * g + 1]);
+        PINN_STASH_ST(reinterpret_cast<u32x4*>(dsp + 512 * g), out.hi);
+        PINN_STASH_ST(reinterpret_cast<u32x4*>(dsp + 512 * g + 256), out.lo);
       });
     } else {
       const float* hp = sx.act(0, H, lane);
+      float* dsp = sx.dact(0, H, lane);
       f32x4 hl[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) load_block(hp, t, hl[t]);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dh[t][r] = one(hl[t][r], dh[t][r]);
+        for (int r = 0; r < 4; ++r) {
+          dh[t][r] = one(hl[t][r], dh[t][r]);
+          if constexpr (S::kActScale != 1.0f) amax = fmaxf(amax, fabsf(dh[t][r]));      // (already in true units)
+        }
         store_block(dsp, t, dh[t]);
       }
     }

@@ -67,6 +67,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_fwd_x3_kernel(Tra
     const StashX sx{(float*)a.b.stash_h, (float*)a.b.stash_v1, (float*)a.b.stash_v2, (float*)a.b.dpre_h, (float*)a.b.dpre_v1, (float*)a.b.dpre_v2,
                     a.b.t16, t16};
 
+    if constexpr (kPack) {
+      // the input rows as a packed group of their own (features 0 .. 7 of 32, the value x / 16: any |x| < 256 survives the
+      // weight-gradient kernel's row scale in fp16): layer 0's weight gradient reads it like any other activation
+      Frag2 fx;
+      static_for<4>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const float v = kq == 0 ? xa[r] : (kq == 1 ? xb[r] : 0.0f);
+        S::template split<r>(v * 0.0625f, 0.0f, fx);
+      });
+      float* xp = packed_ptr((float*)a.b.stash_x, t16, 32, lane);
+      PINN_STASH_ST(reinterpret_cast<u32x4*>(xp), fx.hi);
+      PINN_STASH_ST(reinterpret_cast<u32x4*>(xp + 256), fx.lo);
+    }
     // ------------------------------------------------------------------ forward (activations stashed)
     float u, z;
     forward_pass<S, H, kBits, true, WAVES, kPack>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z, &sx);

@@ -540,7 +540,12 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_p_kernel(WgradPArgs a) 
   constexpr int kMine = (kData + nW - 1) / nW, kW = kMine + 1;                    // DMA instructions per wave and tile (+ the record, by every wave)
   constexpr int kFrags = TI + TJ;                                                 // fragments a wave reads
   constexpr int NB = TI * TJ, kHalf = NB / 2;
-  constexpr int kPer = (kW + NB - 1) / NB, kRd = (4 * kFrags + (NB - kHalf) - 1) / (NB - kHalf);
+#ifdef PINN_ABL_WGP_BURST      // (ablation: all of a tile's pieces behind its first block)
+  constexpr int kPer = kW;
+#else
+  constexpr int kPer = (kW + NB - 1) / NB;
+#endif
+  constexpr int kRd = (4 * kFrags + (NB - kHalf) - 1) / (NB - kHalf);
   extern __shared__ __attribute__((aligned(1024))) char ring[];                   // S stages
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wi = wave / WJ, wj = wave % WJ;
@@ -565,11 +570,11 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_p_kernel(WgradPArgs a) 
 #pragma unroll
   for (int tj = 0; tj < TJ; ++tj) vq[tj] = 0.f;
 
+  // slice s takes the row tiles s, s + n_slices, ...: at any moment the workgroups of a launch read one contiguous window of the
+  // stash (n_slices x 16-32 KB), spread over every HBM channel; contiguous per-slice ranges put 256 streams 3.9 MB apart
   const int slice = blockIdx.x;
-  const long long per = (a.t16 + a.n_slices - 1) / a.n_slices;
-  const long long t_begin = slice * per;
-  long long t_end = t_begin + per;
-  if (t_end > a.t16) t_end = a.t16;
+  const long long n_mine = slice < a.t16 ? (a.t16 - slice + a.n_slices - 1) / a.n_slices : 0;
+  auto tile_of = [&](long long k) { return slice + (k < n_mine ? k : n_mine - 1) * (long long)a.n_slices; };      // (clamped: trailing re-fetches)
 
   // this wave's j-th piece of tile t: piece p = wave + nW j of the tile's kData (wrapping: a wave with one piece fewer fetches
   // an earlier one again -- same bytes to the same place); the last instruction of every wave is the tile's 256-B row record.
@@ -631,19 +636,18 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_p_kernel(WgradPArgs a) 
   auto frag_lo = [](const Regs& r, int f) { return u32x4{r.w[f][2][0], r.w[f][2][1], r.w[f][3][0], r.w[f][3][1]}; };
   auto stage_addr = [&](const char* st) { return (unsigned)(unsigned long long)(lptr_t)st; };
 
-  if (t_begin < t_end) {
-    auto clampt = [&](long long t) { return t < t_end ? t : t_end - 1; };
+  if (n_mine > 0) {
     Regs cur, nxt;
     // S tiles in flight; the first one into registers
 #pragma unroll
-    for (int s = 0; s < S; ++s) static_for<kW>([&](auto jc) { piece(clampt(t_begin + s), ring + s * kStage, jc); });
+    for (int s = 0; s < S; ++s) static_for<kW>([&](auto jc) { piece(tile_of(s), ring + s * kStage, jc); });
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * kW) : "memory");       // this wave's pieces of tile t_begin have landed ...
     __builtin_amdgcn_s_barrier();                                              // ... and so have the other waves'
     asm volatile("" ::: "memory");
     static_for<4 * kFrags>([&](auto jc) { read_one(cur, stage_addr(ring), jc); });
     read_side(cur, ring);
     int s_cur = 0;                     // stage of tile t
-    for (long long t = t_begin; t < t_end; ++t) {
+    for (long long kt = 0; kt < n_mine; ++kt) {
       const int s_next = s_cur + 1 == S ? 0 : s_cur + 1;
       // `cur` (tile t, read from stage s_cur) is complete; this wave's pieces of tile t + 1 have landed.  Past the barrier that
       // holds for every wave: stage s_next can be read, stage s_cur refilled with tile t + S.
@@ -652,7 +656,7 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_p_kernel(WgradPArgs a) 
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      const long long t_fill = clampt(t + S);
+      const long long t_fill = tile_of(kt + S);
       char* st_fill = ring + s_cur * kStage;
       const char* st_next = ring + s_next * kStage;
       const unsigned a_next = stage_addr(st_next);
@@ -719,7 +723,8 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_p_kernel(WgradPArgs a) 
 
   // ---- write this slice's slab; the powers of two of the row scale leave here
   const int E = grad_exponent(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(*a.emax)), 4);
-  const float sw = ldexpf(1.0f, E - a.qboost - 7), sb = ldexpf(1.0f, E - a.qboost - 4);
+  const float sw = ldexpf(1.0f, E - a.qboost - 4 - a.q_log2), sb = ldexpf(1.0f, E - a.qboost - 4);
+  const int ldw = a.ldW ? a.ldW : a.IN, ncol = a.n_cols ? a.n_cols : a.IN;
   const long long so = (long long)slice * a.slab_stride;
   const int fi = tr_feature(i);
 #pragma unroll
@@ -727,10 +732,12 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_p_kernel(WgradPArgs a) 
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
       const int col = j0 + tj * 32 + fi;           // input feature (C/D layout: B's lane = column)
+      if (col < ncol) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i0 + ti * 32 + tr_feature((r & 3) + 8 * (r >> 2) + 4 * hh);      // A's lane = row of the tile
-        a.dW[so + (long long)row * a.IN + col] = acc[ti][tj][r] * sw;
+        for (int r = 0; r < 16; ++r) {
+          const int row = i0 + ti * 32 + tr_feature((r & 3) + 8 * (r >> 2) + 4 * hh);      // A's lane = row of the tile
+          a.dW[so + (long long)row * ldw + col] = acc[ti][tj][r] * sw;
+        }
       }
     }
   if (row_sums) {
@@ -760,7 +767,11 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_p_kernel(WgradPArgs a) 
 template <int TI, int TJ, int WI, int WJ, bool kVQ = false, bool kVR = false>
 static int launch_p(const WgradPArgs& a, hipStream_t st) {
   constexpr int kBlocks = TI * WI + TJ * WJ + (kVR ? TI * WI : 0), kStage = kBlocks * 2048 + 256;
-  constexpr int S = 4 * kStage <= 140 * 1024 ? 4 : 3;      // stages the 160-KB LDS holds (three tiles ahead where four fit)
+#ifdef PINN_ABL_WGP_S
+  constexpr int S = PINN_ABL_WGP_S;
+#else
+  constexpr int S = 3;      // stages: two tiles ahead (measured at 1e6 rows, whole phase: S = 2 1.57 ms, 3 1.50, 4 1.53)
+#endif
   const dim3 grid(a.n_slices, a.OUT / (TI * 32 * WI), a.IN / (TJ * 32 * WJ));
   const size_t lds = (size_t)S * kStage;
   auto k = wgrad_p_kernel<TI, TJ, WI, WJ, kVQ, kVR, S>;
@@ -819,6 +830,8 @@ int dispatch_wgrad_p(const WgradPArgs& a, void* stream) {
   }
   if (to == 8 && ti == 8) return launch_p<4, 4, 2, 2>(a, st);
   if (to == 4 && ti == 4) return launch_p<2, 2, 2, 2>(a, st);
+  if (to == 8 && ti == 1) return launch_p<2, 1, 4, 1>(a, st);      // layer 0 (Q = the packed input rows): H = 256 / 128
+  if (to == 4 && ti == 1) return launch_p<1, 1, 4, 1>(a, st);
   return PINN_E_ARCH;
 }
 
