@@ -19,9 +19,10 @@ value = rows of all ranks * steps / max-over-ranks wall time (weak scaling: rows
 Arithmetic (--precision, default f32x6 = the library default): fp32 in, fp32 out, fp32 accumulation;
 the matrix products run on the 16-bit matrix cores with split operands: two fp16 parts per operand
 (exact power-of-two scales bring them into fp16's range: constants in the forward passes, per row in
-the backward chain, one per call -- from the largest d pre-activation -- in the weight gradients),
-three cross products -- the accuracy of an fp32 matmul (same parity tests and tolerances as the
-exact-fp32 kernels; gradient tensors as close to a float64 autograd as torch's own fp32 autograd).
+the backward chain and -- on the other operand -- in the weight gradients), three cross products -- the
+accuracy of an fp32 matmul (same parity tests and tolerances as the exact-fp32 kernels; gradient
+tensors as close to a float64 autograd as torch's own fp32 autograd).  The training stash holds the
+fp16 fragments themselves (4 B per element, as fp32 did): the weight-gradient kernels read ready operands.
 The exact-fp32 kernels (v_mfma_f32_*_f32), the opt-in bf16-mixed ones and the f32x6g6 variant
 (gradients from three bf16 parts, six products: round 2's first default) are measured beside it
 unless --only.
@@ -186,9 +187,15 @@ def leg_config1(with_cpu):
     m.train_dnn(2); pinn_amd.get_MC_samples(m, ds[2][:256], ds[4], mc_times=2, dropout=0.4); torch.cuda.synchronize()     # warm-up
     t0 = time.perf_counter(); m.train_dnn(100); torch.cuda.synchronize(); t_train = time.perf_counter() - t0
     t0 = time.perf_counter(); pinn_amd.get_MC_samples(m, ds[2], ds[4], mc_times=32, dropout=0.4); t_mc = time.perf_counter() - t0
+    # the reference's real call is train_dnn(4001) / (8001): 2000 steps of the same call show the replayed-graph rate without the
+    # one-off capture (a few ms, a tenth of a 100-step call), next to the launch-by-launch path
+    t0 = time.perf_counter(); m.train_dnn(2000); torch.cuda.synchronize(); t_long = time.perf_counter() - t0
+    m.use_graph = False
+    t0 = time.perf_counter(); m.train_dnn(500); torch.cuda.synchronize(); t_eager = time.perf_counter() - t0
     n_tr, n_te = ds[0].shape[0], ds[2].shape[0]
     r = {"workload": "BASELINE configs[0]: %d train rows, 100 train_dnn epochs, mc_times=32 on %d rows" % (n_tr, n_te),
          "gpu": {"train_dnn_100_s": t_train, "train_samples_per_s": 100 * n_tr / t_train, "us_per_step": t_train / 100 * 1e6,
+                 "us_per_step_2000_steps_graph_replay": t_long / 2000 * 1e6, "us_per_step_launch_by_launch": t_eager / 500 * 1e6,
                  "mc32_s": t_mc, "mc_fwd_passes_per_s": 32 * n_te / t_mc}}
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -421,9 +428,9 @@ def main():
 
     def one_step():
         step_no[0] += 1
-        # ---- train_dnn step (01:949-955)
-        loss = model.train_step_grads(xd, yd, model.row_offset, n_global)
-        dp.allreduce_grads(model.dnn._flat_grad_full, model._group)
+        # ---- train_dnn step (01:949-955): gradients + all-reduce (N > 1: in two parts, the tail under the head's weight-gradient
+        #      kernels -- model._dp_step) + Adam
+        loss = model._dp_step(xd, yd, model.row_offset, n_global, True)
         _lib.check(lib.pinn_adam_step(_ptr(flat), _ptr(model.dnn._flat_grad), _ptr(model._adam_m), _ptr(model._adam_v),
                                       flat.numel(), 0.01, step_no[0], _stream()), "adam")
         # ---- one iteration of each physics-parameter stage (01:1008-1055, 1107-1151, 1354-1391, 1204-1274)
@@ -591,6 +598,18 @@ def main():
             out[name] = o
         model.dnn.set_precision(args.precision)
 
+    if world > 1:
+        # the same step with ONE blocking all-reduce of the whole bucket instead of the overlapped two-part one
+        model.overlap_allreduce = False
+        for _ in range(max(1, args.warmup)):
+            one_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        barrier()
+        out["ms_per_step_blocking_allreduce"] = max_over_ranks(time.perf_counter() - t0) / args.steps * 1e3
+        model.overlap_allreduce = True
     out["config"]["backend"] = dist.get_backend() if world > 1 else "none (single process)"
     out["config"]["world_size"] = world
     out["config"]["rows_per_rank"] = [rows] * world
@@ -606,8 +625,9 @@ def main():
                   "frac": wgrad_bytes / (r["wgrad"]["ms"] * 1e-3) / 1e9 / 8000.0},
         "step": {"bytes": chain_bytes + wgrad_bytes, "achieved": (chain_bytes + wgrad_bytes) / (out["ms_per_step"] * 1e-3) / 1e9,
                  "frac": (chain_bytes + wgrad_bytes) / (out["ms_per_step"] * 1e-3) / 1e9 / 8000.0},
-        "note": "design bytes: stash written once (h and d pre, 3.84 KB/row each + heads), h read back by the chain, both read once by the "
-                "weight-gradient kernels; algorithmic bytes are 36 B/row (roofline.hbm_algorithmic_GBps)"}
+        "note": "design bytes: stash written once (h and d pre as packed fp16 fragments, 3.84 KB/row each + heads), h read back by the chain, "
+                "both read once by the weight-gradient kernels; algorithmic bytes are 36 B/row (roofline.hbm_algorithmic_GBps).  A pure "
+                "LDS-DMA streaming read sustains 6.3 TB/s on this part (profiles/r03/hbm_read_probe.txt): the practical roof for wgrad"}
     if rank == 0 and world == 1 and not args.no_configs:
         del stage_cache
         model._work.clear()
