@@ -272,6 +272,15 @@ void pinn_adam_coeffs(float lr, int step, float* step_size, float* bc2_sqrt);   
 int pinn_adam_step_dev(float* d_params, const float* d_grads, float* d_m, float* d_v, long long n,
                        const float* d_coeffs, const unsigned* d_step_counter, void* stream);
 
+/* pinn_mlp_train_grads + pinn_adam_step_dev as one launch sequence with the optimizer step applied by the gradient reduction's
+ * own launch: one full train_dnn step (01:949-954) with nothing but device state changing, for capture and replay.  Arguments
+ * as for the two calls (drop->d_step_counter is required; d_params is updated in place; d_grads receives the gradients the
+ * step applied).  Bit-identical to the two calls.  PINN_PREC_F32X6 / _G6 on the fused nets (hidden <= 256), PINN_E_ARCH otherwise. */
+int pinn_mlp_train_step_dev(const pinn_net_t* net, float* d_params, const float* d_x, const float* d_y,
+                            long long n_rows, long long n_global, const pinn_dropout_t* drop, float* d_grads,
+                            double* d_loss, void* d_work, size_t work_bytes, float* d_m, float* d_v,
+                            const float* d_coeffs, void* stream);
+
 /* ---- results assembly: create_comprehensive_results_array_v2 (01:1877-2010) -----------------------------------
  * Fills d_out = float64 [n_rows, 22] row-major (the `comprehensive_results` layout scripts 02-05 read):
  *   0-7 inputs and 8 target, de-normalised like sklearn's inverse_transform on float32 (aff->x_*, aff->y_*; 01:1916-1917);

@@ -5,19 +5,16 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "../../include/pinn_hip.h"
+#include "pinn_adam_update.h"
 
 namespace {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float step_size, float bc2_sqrt) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float gi = g[i];
-    float mi = m[i], vi = v[i];
-    mi = mi + 0.1f * (gi - mi);                 // exp_avg.lerp_(grad, 1 - beta1)
-    vi = vi * 0.999f;                           // exp_avg_sq.mul_(beta2)
-    vi = vi + (0.001f * gi) * gi;               //           .addcmul_(grad, grad, value=1-beta2)
-    const float denom = sqrtf(vi) / bc2_sqrt + 1e-8f;
-    p[i] = p[i] - step_size * (mi / denom);     // param.addcdiv_(exp_avg, denom, value=-step_size)
+    float pi = p[i], mi = m[i], vi = v[i];
+    pinn::adam_update(pi, g[i], mi, vi, step_size, bc2_sqrt);
+    p[i] = pi;
     m[i] = mi;
     v[i] = vi;
   }
@@ -30,13 +27,9 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
   const float step_size = coeffs[2 * k], bc2_sqrt = coeffs[2 * k + 1];
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float gi = g[i];
-    float mi = m[i], vi = v[i];
-    mi = mi + 0.1f * (gi - mi);
-    vi = vi * 0.999f;
-    vi = vi + (0.001f * gi) * gi;
-    const float denom = sqrtf(vi) / bc2_sqrt + 1e-8f;
-    p[i] = p[i] - step_size * (mi / denom);
+    float pi = p[i], mi = m[i], vi = v[i];
+    pinn::adam_update(pi, g[i], mi, vi, step_size, bc2_sqrt);
+    p[i] = pi;
     m[i] = mi;
     v[i] = vi;
   }

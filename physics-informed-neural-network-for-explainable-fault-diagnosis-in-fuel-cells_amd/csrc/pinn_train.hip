@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include "pinn_mlp_core.h"
 #include "pinn_wgrad_args.h"
+#include "pinn_adam_update.h"
 
 namespace pinn {
 
@@ -422,6 +423,12 @@ __global__ __launch_bounds__(kThreads, 1) void wgrad_kernel(WgradArgs a) {
 // The slabs are added in float64 (the launch is bound by its 180 MB of slab reads, not by the adds) and rounded to fp32 once:
 // the reduction over slices adds no rounding of its own to what the slice kernels accumulated.
 constexpr int kFinLanes = 8, kFinGroups = 32;
+// pinn_mlp_train_step_dev: the optimizer step in the reduction's launch (p == nullptr: gradients only).  `snap` = the step
+// counter as the forward kernel of this call read it (TrainBuffers::amax + 2): the counter itself moves during this launch.
+struct FinAdam {
+  float* p; float* m; float* v;
+  const float* coeffs; const unsigned* snap;
+};
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f64x4 widen4(const f32x4& v) { return f64x4{(double)v[0], (double)v[1], (double)v[2], (double)v[3]}; }
 __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restrict__ slabs, int n_slices, long long total,
@@ -429,7 +436,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
                                                             long long off_bp, long long off_bv2, float* __restrict__ grads,
                                                             double* __restrict__ loss_out, const unsigned* __restrict__ amax,
                                                             unsigned* __restrict__ range_word, unsigned* __restrict__ step_counter,
-                                                            long long e_lo, long long e_hi, int with_loss) {
+                                                            long long e_lo, long long e_hi, int with_loss, FinAdam ad) {
   // [e_lo, e_hi): the part of the flat gradient this launch reduces (multiples of 4; the whole vector, or the head / the tail
   // of pinn_grad_split); with_loss: the launch that also owns the loss sums, the range record and the step counter (the tail)
   __shared__ f64x4 part[kFinLanes][kFinGroups];
@@ -439,6 +446,11 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
   // pinn_dropout_t.d_step_counter: the gradients of this step are final with this launch; every kernel that read the counter
   // (the chain's dropout pass) ran before it, the optimizer step that reads it next runs behind it
   if (with_loss && step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1u;
+  float step_size = 0.0f, bc2_sqrt = 1.0f;
+  if (ad.p) {
+    const unsigned k = __builtin_amdgcn_readfirstlane(*ad.snap);
+    step_size = ad.coeffs[2 * k]; bc2_sqrt = ad.coeffs[2 * k + 1];
+  }
   const int g = threadIdx.x & (kFinGroups - 1), q = threadIdx.x / kFinGroups;
   // every tensor starts on a multiple of 4 floats, so the two scalar head biases sit at the start of a group whose other
   // three floats are padding
@@ -463,7 +475,14 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
     } else {
 #pragma unroll
       for (int j = 1; j < kFinLanes; ++j) s += part[j][g];
-      *reinterpret_cast<f32x4*>(grads + e) = f32x4{(float)s[0], (float)s[1], (float)s[2], (float)s[3]};
+      const f32x4 gv = f32x4{(float)s[0], (float)s[1], (float)s[2], (float)s[3]};
+      *reinterpret_cast<f32x4*>(grads + e) = gv;
+      if (ad.p) {
+        f32x4 pv = *reinterpret_cast<const f32x4*>(ad.p + e), mv = *reinterpret_cast<const f32x4*>(ad.m + e), vv = *reinterpret_cast<const f32x4*>(ad.v + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { float pj = pv[j], mj = mv[j], vj = vv[j]; adam_update(pj, gv[j], mj, vj, step_size, bc2_sqrt); pv[j] = pj; mv[j] = mj; vv[j] = vj; }
+        *reinterpret_cast<f32x4*>(ad.p + e) = pv; *reinterpret_cast<f32x4*>(ad.m + e) = mv; *reinterpret_cast<f32x4*>(ad.v + e) = vv;
+      }
     }
   }
   if (blockIdx.x == 0 && with_loss) {
@@ -485,6 +504,12 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
       if (threadIdx.x < 4) loss_out[threadIdx.x] = t;    // nll sum, |logvar| sum, (y-u)^2 sum, (sum du)
       if (threadIdx.x == 3) grads[off_bp] = (float)t;    // d loss / d b_p  = sum du
       if (threadIdx.x == 4) grads[off_bv2] = (float)t;   // d loss / d bv_2 = sum dz
+      if (ad.p && (threadIdx.x == 3 || threadIdx.x == 4)) {      // (their groups' padding floats have zero gradient: no update)
+        const long long o = threadIdx.x == 3 ? off_bp : off_bv2;
+        float pj = ad.p[o], mj = ad.m[o], vj = ad.v[o];
+        adam_update(pj, (float)t, mj, vj, step_size, bc2_sqrt);
+        ad.p[o] = pj; ad.m[o] = mj; ad.v[o] = vj;
+      }
     }
   }
 }
@@ -535,7 +560,7 @@ static Workspace plan_workspace(const pinn_net_t* net, long long n_rows) {
   w.off_du = take((size_t)w.t16 * 16 * 4);
   w.off_dz = take((size_t)w.t16 * 16 * 4);
   w.off_loss = take((size_t)1024 * kLossTerms * 8);
-  w.off_amax = take(256);                                   // [0] TrainBuffers::amax, [1] ::emax
+  w.off_amax = take(256);                                   // [0] TrainBuffers::amax, [1] ::emax, [2] the step counter as the forward kernel read it
   w.off_rowmeta = take((size_t)w.t16 * 256);                // struct RowMeta records
   w.off_stash_x = take((size_t)w.t16 * 2048);               // packed input rows (PINN_PREC_F32X6, fused nets)
   const long long t32 = (w.t16 + 1) / 2;
@@ -543,7 +568,10 @@ static Workspace plan_workspace(const pinn_net_t* net, long long n_rows) {
   // own sizes (< 32 768 rows) are bound by the slabs instead -- at 1e4 rows 256 slices wrote 67 MB per 256 x 256 layer and the
   // reduction read 180 MB, 100 of the step's 200 us --: 64 slices there, and the five layers' launches run side by side
   // (fan_out below), 320 workgroups in all
-  const long long cap = w.t16 < kFanOutT16 ? 64 : kMaxSlices;
+  // (fan_out below), 320 workgroups in all; PINN_PREC_F32X6 at H = 256 runs them as ONE launch of 128 x 128 tiles
+  // (wgrad_p_multi_kernel): 32 slices, ~450 workgroups
+  const bool one_launch = net->precision == PINN_PREC_F32X6 && H == 256 && nh - 1 + 3 <= kMaxWgradProblems;
+  const long long cap = w.t16 < kFanOutT16 ? (one_launch ? 32 : 64) : kMaxSlices;
   w.n_slices = (int)(t32 < cap ? (t32 < 1 ? 1 : t32) : cap);
   ParamLayout L{(int)H, (int)nh};
   w.off_slabs = take((size_t)w.n_slices * L.total() * 4);
@@ -619,6 +647,7 @@ int launch_train_bf16(const pinn_net_t* net, const float* d_params, const float*
                       long long n_global, const DropDev& drop, const TrainBuffers& b, unsigned phases, int* grid_out, void* stream);
 int dispatch_wgrad_x6(const WgradArgs& a, int ns, void* stream);   // pinn_x6_wgrad.hip
 int dispatch_wgrad_p(const WgradPArgs& a, void* stream);            // pinn_x6_wgrad.hip: packed operands (PINN_PREC_F32X6, fused nets)
+int dispatch_wgrad_p_multi(const WgradPMulti& m, void* stream);     //   several of them in one launch (small row counts, H = 256)
 }
 
 using namespace pinn;
@@ -635,9 +664,10 @@ extern "C" size_t pinn_train_workspace_bytes(const pinn_net_t* net, long long n_
   return plan_workspace(net, n_rows).total;
 }
 
-extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y,
-                                           long long n_rows, long long n_global, const pinn_dropout_t* drop, float* d_grads,
-                                           double* d_loss, void* d_work, size_t work_bytes, void* stream, unsigned phases) {
+// fa: the optimizer step in the reduction's launch (pinn_mlp_train_step_dev), or nullptr
+static int train_grads_impl(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y,
+                            long long n_rows, long long n_global, const pinn_dropout_t* drop, float* d_grads,
+                            double* d_loss, void* d_work, size_t work_bytes, void* stream, unsigned phases, const FinAdam* fa) {
   int rc = check_net_t(net);
   if (rc) return rc;
   if (!d_params || !d_x || !d_y || !d_grads || !d_loss || !d_work || n_rows <= 0 || n_global < n_rows) return PINN_E_ARG;
@@ -661,6 +691,8 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
   char* base = (char*)d_work;
   const int H = net->hidden, nh = net->n_hidden;
   ParamLayout L{H, nh};
+  FinAdam fin_adam{};
+  if (fa) { fin_adam = *fa; fin_adam.snap = (const unsigned*)(base + w.off_amax) + 2; }
 
   TrainArgs a{};
   a.params = d_params; a.x = d_x; a.y = d_y; a.n_rows = n_rows; a.n_global = n_global; a.H = H; a.nh = nh;
@@ -710,7 +742,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     if (phases & PINN_PHASE_REDUCE)
       hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((L.total() / 4 + kFinGroups - 1) / kFinGroups)), dim3(256), 0, st, b.slabs, w.n_slices,
                          L.total(), a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss, (const unsigned*)nullptr, (unsigned*)nullptr, a.drop.step_counter,
-                         0LL, (long long)L.total(), 1);
+                         0LL, (long long)L.total(), 1, FinAdam{});
     hipError_t eb = hipGetLastError();
     return eb == hipSuccess ? PINN_OK : (int)eb;
   }
@@ -754,7 +786,8 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     const bool do_tail = phases & PINN_PHASE_WGRAD_TAIL, do_head = phases & PINN_PHASE_WGRAD_HEAD;
     auto in_part = [&](int l) { return l == nh - 1 ? do_tail : do_head; };      // hidden layer l >= 1
     // small row counts: the launches of the layers are independent and short -- side by side on up to four streams
-    const bool fan = w.t16 < kFanOutT16 && g_fan.init();
+    const bool multi = w.t16 < kFanOutT16 && net->precision == PINN_PREC_F32X6 && H == 256 && nh - 1 + 3 <= kMaxWgradProblems;
+    const bool fan = !multi && w.t16 < kFanOutT16 && g_fan.init();
     int n_launch = 0;
     bool used[3] = {false, false, false};
     if (fan && hipEventRecord(g_fan.fork, st) != hipSuccess) return (int)hipGetLastError();
@@ -764,6 +797,12 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
       if (k == 0) return st;
       if (!used[k - 1]) { (void)hipStreamWaitEvent(g_fan.side[k - 1], g_fan.fork, 0); used[k - 1] = true; }
       return g_fan.side[k - 1];
+    };
+    WgradPMulti mp{};
+    auto issue_p = [&](const WgradPArgs& pa, int kind) -> int {
+      if (!multi) return dispatch_wgrad_p(pa, (void*)pick());
+      mp.p[mp.n] = pa; mp.kind[mp.n] = kind; ++mp.n;
+      return PINN_OK;
     };
     WgradArgs g{};
     g.x = d_x; g.n_rows = n_rows; g.t16 = w.t16; g.n_slices = w.n_slices; g.slab_stride = tot;
@@ -787,24 +826,25 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
         // |x| < 256 survives the row scale in fp16); [H][8] of the [H][32] product is written
         p.P = (const char*)a.dpre_h; p.Q = (const char*)(base + w.off_stash_x); p.OUT = H; p.IN = 32; p.dW = slabs + L.w0(); p.db = slabs + L.b0();
         p.ldW = 8; p.n_cols = 8; p.q_log2 = -4;
-        if ((rc = dispatch_wgrad_p(p, (void*)pick()))) return rc;
+        if ((rc = issue_p(p, 0))) return rc;
         p.ldW = 0; p.n_cols = 0; p.q_log2 = 3;
       }
       for (int l = nh - 1; l >= 1; --l) {
         if (!in_part(l)) continue;
         p.P = (const char*)a.dpre_h + l * hb; p.Q = (const char*)a.stash_h + (l - 1) * hb; p.OUT = H; p.IN = H; p.dW = slabs + L.w(l); p.db = slabs + L.b(l);
-        if ((rc = dispatch_wgrad_p(p, (void*)pick()))) return rc;
+        if ((rc = issue_p(p, 1))) return rc;
       }
       if (do_tail) {
         // variance head layer 0 (+ predict weight: dw_p[j] = sum du * h_last[j])
         p.P = (const char*)a.dpre_v1; p.Q = (const char*)a.stash_h + (nh - 1) * hb; p.OUT = H / 2; p.IN = H; p.dW = slabs + L.wv0(); p.db = slabs + L.bv0();
         p.dvq = slabs + L.wp();
-        if ((rc = dispatch_wgrad_p(p, (void*)pick()))) return rc;
+        if ((rc = issue_p(p, 2))) return rc;
         // variance head layer 1 (+ final weight: dwv2[i] = sum dz * v2[i], fp32 operands)
         p.P = (const char*)a.dpre_v2; p.Q = (const char*)a.stash_v1; p.OUT = H / 4; p.IN = H / 2; p.dW = slabs + L.wv1(); p.db = slabs + L.bv1();
         p.dvq = nullptr; p.s2 = a.dz; p.R = a.stash_v2; p.dvr = slabs + L.wv2();
-        if ((rc = dispatch_wgrad_p(p, (void*)pick()))) return rc;
+        if ((rc = issue_p(p, 3))) return rc;
       }
+      if (multi && mp.n > 0 && (rc = dispatch_wgrad_p_multi(mp, (void*)st))) return rc;
     } else {
     const int ns = net->precision == PINN_PREC_F32X6 ? 4 : (net->precision == PINN_PREC_F32X6_G6 ? 3 : (net->precision == PINN_PREC_BF16 ? 1 : 0));
     auto wgrad = [&](const WgradArgs& wa) { hipStream_t s_ = pick(); return ns ? dispatch_wgrad_x6(wa, ns, (void*)s_) : dispatch_wgrad(wa, s_); };
@@ -836,7 +876,7 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
     auto reduce = [&](long long lo, long long hi, int with_loss) {
       hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)(((hi - lo) / 4 + kFinGroups - 1) / kFinGroups)), dim3(256), 0, st, slabs, w.n_slices, tot,
                          a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss, (const unsigned*)(base + w.off_amax), rw, a.drop.step_counter, lo, hi,
-                         with_loss);
+                         with_loss, fin_adam);
     };
     if (both) reduce(0, tot, 1);                               // one launch over the whole vector
     else if (phases & PINN_PHASE_REDUCE_TAIL) reduce(split, tot, 1);
@@ -844,6 +884,26 @@ extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;
+}
+
+extern "C" int pinn_mlp_train_grads_phases(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y,
+                                           long long n_rows, long long n_global, const pinn_dropout_t* drop, float* d_grads,
+                                           double* d_loss, void* d_work, size_t work_bytes, void* stream, unsigned phases) {
+  return train_grads_impl(net, d_params, d_x, d_y, n_rows, n_global, drop, d_grads, d_loss, d_work, work_bytes, stream, phases, nullptr);
+}
+
+// One optimizer step of train_dnn (01:949-954) as ONE launch sequence that can be captured and replayed: pinn_mlp_train_grads
+// with the Adam step applied by the slab reduction's own launch (at the reference's row counts a step is a chain of short
+// dependent launches, and the separate optimizer launch was 5 of its ~130 us).  d_params is updated in place.
+extern "C" int pinn_mlp_train_step_dev(const pinn_net_t* net, float* d_params, const float* d_x, const float* d_y,
+                                       long long n_rows, long long n_global, const pinn_dropout_t* drop, float* d_grads,
+                                       double* d_loss, void* d_work, size_t work_bytes, float* d_m, float* d_v,
+                                       const float* d_coeffs, void* stream) {
+  if (!net || !drop || !drop->d_step_counter || !d_m || !d_v || !d_coeffs) return PINN_E_ARG;
+  if (!(net->precision >= PINN_PREC_F32X6 && net->hidden <= 256)) return PINN_E_ARCH;      // (the kernels that leave the counter's snapshot)
+  if (((unsigned long long)d_params | (unsigned long long)d_m | (unsigned long long)d_v) & 15) return PINN_E_ARG;
+  const FinAdam fa{d_params, d_m, d_v, d_coeffs, nullptr};
+  return train_grads_impl(net, d_params, d_x, d_y, n_rows, n_global, drop, d_grads, d_loss, d_work, work_bytes, stream, PINN_PHASE_ALL, &fa);
 }
 
 extern "C" int pinn_mlp_train_grads(const pinn_net_t* net, const float* d_params, const float* d_x, const float* d_y,

@@ -38,4 +38,13 @@ struct WgradPArgs {
   const float* s2; const float* R; float* dvr;    // optional: dvr[i] = sum_rows dz[row] R[i][row]   (R fp32 [T16][OUT][16]; dz from the meta records, s2 only says so)
 };
 
+// several packed weight-gradient problems in one launch (small row counts, H = 256: pinn_x6_wgrad.hip wgrad_p_multi_kernel)
+constexpr int kMaxWgradProblems = 12;
+struct WgradPMulti {
+  WgradPArgs p[kMaxWgradProblems];
+  int kind[kMaxWgradProblems];        // 0 layer 0, 1 hidden [256][256], 2 variance head 0 (+ predict weight), 3 variance head 1 (+ last weight)
+  int first[kMaxWgradProblems + 1];   // (filled by the launcher) first workgroup of problem k
+  int n;
+};
+
 }  // namespace pinn

@@ -23,6 +23,7 @@ struct PackJobs6 {
   int n;
   long long copy_stride;
   int with_f16;          // also the two fp16 copies (scheme X3)
+  int with_bf16;         // the three bf16 copies (scheme X6: only PINN_PREC_F32X6_G6's gradient kernels read them)
 };
 
 static int cu_count_x() { return cu_count_cached(); }
@@ -36,29 +37,46 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(const float* __restrict__ 
                                                       unsigned* __restrict__ status, unsigned* __restrict__ zero_word) {
   if (zero_word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_word = 0u;      // TrainBuffers::emax, for the forward kernel behind us
   const PackJob j = jobs.j[blockIdx.y];
-  const long long n = (long long)j.rows * j.Kp;
+  const long long n2 = (long long)j.rows * j.Kp / 2;      // pairs of consecutive packed positions (Kp is a multiple of 64)
   int bad = 0;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
-    const int row = (int)(e / j.Kp), q = (int)(e % j.Kp);
+  auto src_of = [&](int row, int q) -> float {
     const int k = (q & ~31) + pack_col_x6(q & 31);
-    float v = 0.0f;
-    if (k < j.K) v = j.transposed ? params[j.src + (long long)k * j.src_ld + row] : params[j.src + (long long)row * j.src_ld + k];
-    const __bf16 h = (__bf16)v;
-    const float r1 = v - (float)h;
-    const __bf16 m = (__bf16)r1;
-    const float r2 = r1 - (float)m;
-    packed[j.dst + e] = h;
-    packed[jobs.copy_stride + j.dst + e] = m;
-    packed[2 * jobs.copy_stride + j.dst + e] = (__bf16)r2;
+    if (k >= j.K) return 0.0f;
+    return j.transposed ? params[j.src + (long long)k * j.src_ld + row] : params[j.src + (long long)row * j.src_ld + k];
+  };
+  for (long long e2 = (long long)blockIdx.x * blockDim.x + threadIdx.x; e2 < n2; e2 += (long long)gridDim.x * blockDim.x) {
+    const long long e = 2 * e2;
+    const int row = (int)(e / j.Kp), q = (int)(e % j.Kp);
+    const float v[2] = {src_of(row, q), src_of(row, q + 1)};
+    if (jobs.with_bf16) {          // three bf16 copies, w = hi + mid + lo exactly (scheme X6: PINN_PREC_F32X6_G6's gradients)
+      __bf16 h[2], m[2], l[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        h[t] = (__bf16)v[t];
+        const float r1 = v[t] - (float)h[t];
+        m[t] = (__bf16)r1;
+        l[t] = (__bf16)(r1 - (float)m[t]);
+      }
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<bf16x2_t*>(packed + j.dst + e) = bf16x2_t{h[0], h[1]};
+      *reinterpret_cast<bf16x2_t*>(packed + jobs.copy_stride + j.dst + e) = bf16x2_t{m[0], m[1]};
+      *reinterpret_cast<bf16x2_t*>(packed + 2 * jobs.copy_stride + j.dst + e) = bf16x2_t{l[0], l[1]};
+    }
     // every matrix again as two fp16 copies of X3::kWScale * w (scheme X3: forward and backward chain), behind the three
-    // bf16 copies (weight gradients): same element offsets, same K permutation
+    // bf16 copies: same element offsets, same K permutation
     if (jobs.with_f16) {
       _Float16* p16 = reinterpret_cast<_Float16*>(packed + 3 * jobs.copy_stride);
-      const float vs = v * X3::kWScale;
-      bad |= !(fabsf(vs) <= 65504.0f);           // (also true for a NaN)
-      const _Float16 h16 = (_Float16)vs;
-      p16[j.dst + e] = h16;
-      p16[jobs.copy_stride + j.dst + e] = (_Float16)(vs - (float)h16);
+      _Float16 h16[2], l16[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float vs = v[t] * X3::kWScale;
+        bad |= !(fabsf(vs) <= 65504.0f);           // (also true for a NaN)
+        h16[t] = (_Float16)vs;
+        l16[t] = (_Float16)(vs - (float)h16[t]);
+      }
+      typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<f16x2_t*>(p16 + j.dst + e) = f16x2_t{h16[0], h16[1]};
+      *reinterpret_cast<f16x2_t*>(p16 + jobs.copy_stride + j.dst + e) = f16x2_t{l16[0], l16[1]};
     }
   }
   if (status) {
@@ -90,6 +108,7 @@ void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st
   jobs.n = n;
   jobs.copy_stride = K.total();
   jobs.with_f16 = 1;
+  jobs.with_bf16 = net->precision != PINN_PREC_F32X6;      // (_G6: scheme X6 gradients; PINN_PREC_BF16 on the wide nets: the first copy)
   static_assert(kRangeStatusBytes >= (18 * kRangePackBlocks + 1) * sizeof(unsigned), "range record too small");
   hipLaunchKernelGGL(pack_x6_kernel, dim3(kRangePackBlocks, n), dim3(256), 0, st, d_params, (__bf16*)net->d_packed, jobs, range_status_words(net), zero_word);
 }

@@ -134,7 +134,9 @@ struct PipeT {
     const int copy = p >> m.nrb_log, rb = p & ((1 << m.nrb_log) - 1);
     const unsigned soff = (unsigned)copy * copy_bytes + 2u * (m.off + 32u * (unsigned)g + ((unsigned)(rb * 16) << kp));
     char* dst = lds + buf * kSlab + copy * kCopyLds + rb * 1024;
+#ifndef PINN_ABL_NOPIECE      // (ablation: what a slab step costs without its LDS-DMA instructions; results are garbage)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, voff, soff, 0, 0);
+#endif
   }
   // The same for a matrix whose shape is a compile-time constant with at least WAVES 16-row blocks per copy (NRB_LOG =
   // log2 of them): piece WAVES * J + wave is (copy, row block) = (static, static + wave), so the scalar offset is the
@@ -150,7 +152,9 @@ struct PipeT {
     const unsigned voff = (lane_row2 << KP_LOG) + lane_kq8;
     const unsigned soff = mbase + (unsigned)copy * copy_bytes + 64u * (unsigned)g + ((unsigned)(rb0 * 32) << KP_LOG);
     char* dst = lds + buf * kSlab + wave * 1024 + copy * kCopyLds + rb0 * 1024;
+#ifndef PINN_ABL_NOPIECE
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, voff, soff, 0, 0);
+#endif
   }
   // slab 0 of the sequence
   template <int KP_LOG, int WAVES = 8>
@@ -180,6 +184,19 @@ struct PipeT {
   }
 };
 using Pipe6 = PipeT<3>;
+
+// Small row counts (one wave per SIMD, fewer workgroups than CUs): a slab's multiply phase is ~0.4 us, the request for the
+// next slab goes out inside it, and the packed weights were written by another kernel a moment ago -- every slab is a first
+// touch for this XCD's L2, and all its workgroups walk the slab sequence in step, so every slab step waits out the miss.
+// The workgroups of an XCD (round-robin dispatch: blockIdx.x % 8) therefore split one sweep over the weight copies at kernel
+// start: one dword per 128-B line by LDS-DMA into a dummy (no registers to keep alive; retired by the first barrier).
+template <int kThreads>
+__device__ __forceinline__ void l2_warm(const void* base, unsigned bytes, char* lds_dummy) {
+  const unsigned n_wg = (gridDim.x + 7) / 8, r = blockIdx.x / 8;
+  const unsigned lines = bytes / 128;
+  for (unsigned i = r * kThreads + threadIdx.x; i < lines; i += n_wg * kThreads)
+    __builtin_amdgcn_global_load_lds((gptr_t)((const char*)base + (size_t)i * 128), (lptr_t)lds_dummy, 4, 0, 0);
+}
 
 // three bf16 fragments of the 8 fp32 values a lane holds in one 32-group: v = hi + mid + lo (exact)
 // K order inside a 32-group for the x6 kernels: B-fragment element jj = 2 r + b of lane group kq is feature

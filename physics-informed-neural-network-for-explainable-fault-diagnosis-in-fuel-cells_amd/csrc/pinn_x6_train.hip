@@ -41,6 +41,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_fwd_x3_kernel(Tra
   char* lds_w = smem + kSlabAt;
   ParamLayout L{a.H, a.nh};
   PackLayout K{a.H, a.nh};
+#ifdef PINN_SMALLN_WARM
+  if constexpr (WAVES == 4) l2_warm<kThreadsX>(packed + 3 * K.total(), (unsigned)(K.total() * 4), lds_w + S::Pipe::kSlab);
+#endif
   fill_small<S, kThreadsX>(small, w0t, a.params, L);
   S::Pipe pipe;
   pipe.lds = lds_w;
@@ -55,6 +58,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_fwd_x3_kernel(Tra
 
   const long long n_tiles = (a.n_rows + 127) / 128 * (128 / kTileRowsX);      // whole 128-row stash tiles
   const unsigned pass0 = train_pass(a.drop);      // 0, or the device's step counter (replayed graphs)
+  // ... which the reduction advances while its own workgroups still need the old value (pinn_mlp_train_step_dev): a copy
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.b.amax[2] = pass0;
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long t16 = tile * WAVES + wave;
     const long long lrow = t16 * 16 + (lane & 15);
@@ -153,6 +158,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void train_bwd_kernel(TrainA
   char* lds_w = smem + kSlabAt;
   ParamLayout L{a.H, a.nh};
   PackLayout K{a.H, a.nh};
+#ifdef PINN_SMALLN_WARM
+  if constexpr (WAVES == 4 && S::kCopies == 2) l2_warm<kThreadsX>(packed + 3 * K.total(), (unsigned)(K.total() * 4), lds_w + S::Pipe::kSlab);
+#endif
   fill_small<X6, kThreadsX>(small, w0t, a.params, L);                        // (the backward pass reads head vectors only: no scaled biases)
   typename S::Pipe pipe;
   pipe.lds = lds_w;

@@ -533,7 +533,7 @@ __device__ __forceinline__ float dot8(const u32x4& v, const u32x4& w, float acc)
 // cut into its TI x TJ blocks of three MFMAs; every block carries its share of tile t + S's pieces and, in the second half,
 // of tile t + 1's transposing reads, pinned with sched_barrier.
 template <int TI, int TJ, int WI, int WJ, bool kVQ, bool kVR, int S>
-__global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_p_kernel(WgradPArgs a) {
+__device__ __forceinline__ void wgrad_p_body(const WgradPArgs& a, const int slice, const int by, const int bz, char* ring) {
   constexpr int nW = WI * WJ, GP = TI * WI, GQ = TJ * WJ, GR = kVR ? GP : 0;      // the workgroup's blocks of a tile: P, Q, R groups
   constexpr int kBlocks = GP + GQ + GR, kData = 2 * kBlocks;                      // 2-KB blocks, 1-KB data pieces per tile
   constexpr int kMetaAt = kBlocks * 2048, kStage = kMetaAt + 256;                 // + the tile's row record
@@ -546,13 +546,12 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_p_kernel(WgradPArgs a) 
   constexpr int kPer = (kW + NB - 1) / NB;
 #endif
   constexpr int kRd = (4 * kFrags + (NB - kHalf) - 1) / (NB - kHalf);
-  extern __shared__ __attribute__((aligned(1024))) char ring[];                   // S stages
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (ring: S stages)
   const int wi = wave / WJ, wj = wave % WJ;
   const int hh = lane >> 5, i = lane & 31;
-  const int gi0 = blockIdx.y * GP, gj0 = blockIdx.z * GQ;                         // the workgroup's first 32-feature group of P / of Q
+  const int gi0 = by * GP, gj0 = bz * GQ;                                         // the workgroup's first 32-feature group of P / of Q
   const int i0 = 32 * (gi0 + wi * TI), j0 = 32 * (gj0 + wj * TJ);                 // this wave's first output row / column
-  const bool row_sums = wj == 0 && blockIdx.z == 0, col_sums = wi == 0 && blockIdx.y == 0;
+  const bool row_sums = wj == 0 && bz == 0, col_sums = wi == 0 && by == 0;
   const bool want_q = kVQ && col_sums && a.dvq;
   const int gP = a.OUT / 32, gQ = a.IN / 32;
 
@@ -572,7 +571,6 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_p_kernel(WgradPArgs a) 
 
   // slice s takes the row tiles s, s + n_slices, ...: at any moment the workgroups of a launch read one contiguous window of the
   // stash (n_slices x 16-32 KB), spread over every HBM channel; contiguous per-slice ranges put 256 streams 3.9 MB apart
-  const int slice = blockIdx.x;
   const long long n_mine = slice < a.t16 ? (a.t16 - slice + a.n_slices - 1) / a.n_slices : 0;
   auto tile_of = [&](long long k) { return slice + (k < n_mine ? k : n_mine - 1) * (long long)a.n_slices; };      // (clamped: trailing re-fetches)
 
@@ -764,6 +762,65 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_p_kernel(WgradPArgs a) 
   }
 }
 
+template <int TI, int TJ, int WI, int WJ, bool kVQ, bool kVR, int S>
+__global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_p_kernel(WgradPArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char ring[];
+  wgrad_p_body<TI, TJ, WI, WJ, kVQ, kVR, S>(a, blockIdx.x, blockIdx.y, blockIdx.z, ring);
+}
+
+// Small row counts (the reference's own: 1e3 .. 3e4 rows), H = 256: every layer's gradient in ONE launch.  Five launches
+// side by side on forked streams cost ~8 us at the fork and ~10 us at the join inside a replayed graph, and a workgroup that
+// owns a whole 256 x 256 gradient spends more time zeroing and writing its 256 accumulator registers than multiplying.  Here a
+// workgroup is (problem, slice, 128 x 128 or smaller output tile): four waves, <= 64 accumulator registers, ~450 workgroups
+// resident at once.  Same arithmetic per output element as the per-layer launches (the K order of a slice is the same).
+template <int S>
+__global__ __launch_bounds__(256, 2) void wgrad_p_multi_kernel(WgradPMulti m) {
+  extern __shared__ __attribute__((aligned(1024))) char ring[];
+  const int b = blockIdx.x;
+  int k = 0;
+  while (k + 1 < m.n && b >= m.first[k + 1]) ++k;
+  k = __builtin_amdgcn_readfirstlane(k);
+  const WgradPArgs& a = m.p[k];
+  const int local = b - m.first[k];
+  const int slice = local % a.n_slices, t = local / a.n_slices;
+  const int kind = m.kind[k];
+  if (kind == 0) wgrad_p_body<2, 1, 4, 1, false, false, S>(a, slice, 0, 0, ring);                 // layer 0: [256][32 -> 8]
+  else if (kind == 1) wgrad_p_body<2, 2, 2, 2, false, false, S>(a, slice, t & 1, t >> 1, ring);    // hidden: four 128 x 128 tiles
+  else if (kind == 2) wgrad_p_body<1, 2, 2, 2, true, false, S>(a, slice, t & 1, t >> 1, ring);     // variance head 0 (+ predict weight): four 64 x 128 tiles
+  else wgrad_p_body<1, 2, 2, 2, false, true, S>(a, slice, 0, 0, ring);                             // variance head 1 (+ last weight): [64][128]
+}
+
+int launch_wgrad_p_multi(const WgradPMulti& m_in, hipStream_t st) {
+  constexpr int S = 3;
+  WgradPMulti m = m_in;
+  int nb = 0;
+  size_t lds = 0;
+  for (int k = 0; k < m.n; ++k) {
+    const WgradPArgs& a = m.p[k];
+    if (!a.P || !a.Q || !a.meta || !a.emax) return PINN_E_ARG;
+    int tiles = 1, blocks = 0;
+    const int to = a.OUT / 32, ti = a.IN / 32;
+    if (m.kind[k] == 0) { if (to != 8 || ti != 1) return PINN_E_ARCH; blocks = 8 + 1; }
+    else if (m.kind[k] == 1) { if (to != 8 || ti != 8) return PINN_E_ARCH; tiles = 4; blocks = 4 + 4; }
+    else if (m.kind[k] == 2) { if (to != 4 || ti != 8 || !a.dvq) return PINN_E_ARCH; tiles = 4; blocks = 2 + 4; }
+    else { if (to != 2 || ti != 4 || !a.dvr || !a.R || !a.s2) return PINN_E_ARCH; blocks = 2 + 4 + 2; }
+    m.first[k] = nb;
+    nb += tiles * a.n_slices;
+    const size_t need = (size_t)S * (blocks * 2048 + 256);
+    lds = need > lds ? need : lds;
+  }
+  m.first[m.n] = nb;
+  auto kfn = wgrad_p_multi_kernel<S>;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * (9 * 2048 + 256)));
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(kfn, dim3(nb), dim3(256), lds, st, m);
+  return PINN_OK;
+}
+
 template <int TI, int TJ, int WI, int WJ, bool kVQ = false, bool kVR = false>
 static int launch_p(const WgradPArgs& a, hipStream_t st) {
   constexpr int kBlocks = TI * WI + TJ * WJ + (kVR ? TI * WI : 0), kStage = kBlocks * 2048 + 256;
@@ -834,5 +891,7 @@ int dispatch_wgrad_p(const WgradPArgs& a, void* stream) {
   if (to == 4 && ti == 1) return launch_p<1, 1, 4, 1>(a, st);
   return PINN_E_ARCH;
 }
+
+int dispatch_wgrad_p_multi(const WgradPMulti& m, void* stream) { return x6::launch_wgrad_p_multi(m, (hipStream_t)stream); }
 
 }  // namespace pinn

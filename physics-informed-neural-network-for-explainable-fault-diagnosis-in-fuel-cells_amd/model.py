@@ -452,7 +452,14 @@ class PhysicsInformedNN():
         drop.d_step_counter = counter.data_ptr()
         net = self.dnn._net
 
+        one_call = net.precision in (_lib.PREC_F32X6, _lib.PREC_F32X6_G6)       # the reduction's launch applies the Adam step too
+
         def step():
+            if one_call:
+                _lib.check(self._lib.pinn_mlp_train_step_dev(ctypes.byref(net), _ptr(flat), _ptr(x), _ptr(y), n, int(n_norm), ctypes.byref(drop),
+                                                             _ptr(grad), _ptr(loss), _ptr(work), work.numel(), _ptr(self._adam_m),
+                                                             _ptr(self._adam_v), _ptr(d_coeffs), _stream()), "pinn_mlp_train_step_dev")
+                return
             _lib.check(self._lib.pinn_mlp_train_grads(ctypes.byref(net), _ptr(flat), _ptr(x), _ptr(y), n, int(n_norm), ctypes.byref(drop),
                                                       _ptr(grad), _ptr(loss), _ptr(work), work.numel(), _stream()), "pinn_mlp_train_grads")
             _lib.check(self._lib.pinn_adam_step_dev(_ptr(flat), _ptr(grad), _ptr(self._adam_m), _ptr(self._adam_v), flat.numel(),
@@ -460,15 +467,31 @@ class PhysicsInformedNN():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             step()
-        for epoch in range(1, epochs):
-            graph.replay()
-            if epoch % 1000 == 0:
-                log(epoch, loss)
+        # a graph launch costs ~8 us of idle GPU between two replays (a fifteenth of a step at 1e4 rows): long calls replay
+        # kChunk steps per launch wherever no log line falls inside the chunk (a line reads the loss of ITS step)
+        kChunk = self.graph_chunk
+        chunk = None
+        if epochs - 1 >= 4 * kChunk:
+            chunk = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(chunk):
+                for _ in range(kChunk):
+                    step()
+        epoch = 1
+        while epoch < epochs:
+            next_log = (epoch + 999) // 1000 * 1000          # the first epoch >= this one that prints a line
+            if chunk is not None and epoch + kChunk <= epochs and next_log >= epoch + kChunk - 1:
+                chunk.replay()
+                epoch += kChunk
+            else:
+                graph.replay()
+                epoch += 1
+            if (epoch - 1) % 1000 == 0:
+                log(epoch - 1, loss)
         torch.cuda.current_stream().synchronize()
         self._step_counter += epochs - 1
         if training and self.dnn._mask_bits is not None:
             self.dnn._mask_pass += epochs - 1
-        self._keep_alive = (d_coeffs, counter, work, loss, graph)      # until the next call: the stream may still be replaying
+        self._keep_alive = (d_coeffs, counter, work, loss, graph, chunk)      # until the next call: the stream may still be replaying
         return loss
 
     def train_dnn(self, nIter, batch_size=None):
@@ -571,6 +594,7 @@ class PhysicsInformedNN():
                 log_fn(epoch, loss.cpu().numpy(), self._sums.cpu().numpy(), lr0 * gamma ** ((epoch + 1) // 1000))
         self.last_loss = float(loss[0].item()) if nIter > 0 else None
 
+    graph_chunk = 8                 # train_dnn steps per graph launch in long replayed calls
     stage_run_max_rows = 32768      # <= _lib.STAGE_RUN_MAX_ROWS; larger series iterate the multi-workgroup kernels
     _lambda_log_view = None
 

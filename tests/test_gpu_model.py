@@ -342,6 +342,7 @@ def test_train_dnn_graph_replay_is_bit_identical(precision, H):
         m = pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, H, H, H, 1], ds[4], ds[5], p=0.2, logvar=True, seed=31, precision=precision)
         m.verbose = False
         m.use_graph = use_graph
+        m.graph_chunk = 2                  # long calls replay several steps per graph launch: exercised here at 9 steps
         if bits is not None:
             m.dnn.inject_masks(bits)
         m.train_dnn(steps)
