@@ -45,7 +45,7 @@ struct LayerArgs {
   long long n_rows, row_base;   // rows of this launch; global index of its first row (Philox) = drop.row_offset + chunk start
   int IN, OUT;
   unsigned mat_off;          // bf16-element offset of the [OUT][IN] matrix inside a copy
-  int kp_log;                // log2 of its row stride
+  int kp_log;                // log2 of OUT: the group stride of the group-major copies is OUT x 32 elements (set by launch_layer)
   long long bias_off;        // float offset of the bias in params (EPI_TANH*)
   int layer;                 // dropout module index
   DropDev drop;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
   const int lane = threadIdx.x & 63, wave = pipe.wave, kq = lane >> 4;
   const StashRing ring{smem + wave * 4096, lane};
   const int NG = a.IN / 32, nob = a.OUT / kOB;
-  auto slab_mat = [&](int ob) { return Mat{a.mat_off + ((unsigned)(ob * kOB) << a.kp_log), kNrb, a.kp_log}; };      // the rows of pass ob
+  auto slab_mat = [&](int ob) { return Mat{a.mat_off + (unsigned)(ob * kOB) * 32u, kNrb, 0, a.kp_log}; };      // the rows of pass ob
   // slab (0, 0)
   pipe.par = 0;
   for (int j = 0; j < kPieces; ++j) pipe.template piece<-1>(slab_mat(0), 0, j, 0);
@@ -420,6 +420,7 @@ void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st
 // PINN_PREC_BF16: one bf16 part per operand everywhere (the first bf16 copy)
 template <int EPI>
 static void launch_wide_layer(wide::LayerArgs la, int grid, hipStream_t st, int precision) {
+  la.kp_log = 31 - __builtin_clz((unsigned)la.OUT);      // group-major weight copies: group stride = OUT x 32 elements
   if (precision == PINN_PREC_BF16) {
     if (la.OUT % 256 == 0) hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::B1, EPI, 16>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
     else hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::B1, EPI, 8>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);

@@ -48,6 +48,8 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(const float* __restrict__ 
     const long long e = 2 * e2;
     const int row = (int)(e / j.Kp), q = (int)(e % j.Kp);
     const float v[2] = {src_of(row, q), src_of(row, q + 1)};
+    // group-major: [K-group q / 32][row][32] (pinn_x6_core.h PipeT::piece)
+    const long long at = (long long)(q >> 5) * j.rows * 32 + (long long)row * 32 + (q & 31);
     if (jobs.with_bf16) {          // three bf16 copies, w = hi + mid + lo exactly (scheme X6: PINN_PREC_F32X6_G6's gradients)
       __bf16 h[2], m[2], l[2];
 #pragma unroll
@@ -58,9 +60,9 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(const float* __restrict__ 
         l[t] = (__bf16)(r1 - (float)m[t]);
       }
       typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-      *reinterpret_cast<bf16x2_t*>(packed + j.dst + e) = bf16x2_t{h[0], h[1]};
-      *reinterpret_cast<bf16x2_t*>(packed + jobs.copy_stride + j.dst + e) = bf16x2_t{m[0], m[1]};
-      *reinterpret_cast<bf16x2_t*>(packed + 2 * jobs.copy_stride + j.dst + e) = bf16x2_t{l[0], l[1]};
+      *reinterpret_cast<bf16x2_t*>(packed + j.dst + at) = bf16x2_t{h[0], h[1]};
+      *reinterpret_cast<bf16x2_t*>(packed + jobs.copy_stride + j.dst + at) = bf16x2_t{m[0], m[1]};
+      *reinterpret_cast<bf16x2_t*>(packed + 2 * jobs.copy_stride + j.dst + at) = bf16x2_t{l[0], l[1]};
     }
     // every matrix again as two fp16 copies of X3::kWScale * w (scheme X3: forward and backward chain), behind the three
     // bf16 copies: same element offsets, same K permutation
@@ -75,8 +77,8 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(const float* __restrict__ 
         l16[t] = (_Float16)(vs - (float)h16[t]);
       }
       typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-      *reinterpret_cast<f16x2_t*>(p16 + j.dst + e) = f16x2_t{h16[0], h16[1]};
-      *reinterpret_cast<f16x2_t*>(p16 + jobs.copy_stride + j.dst + e) = f16x2_t{l16[0], l16[1]};
+      *reinterpret_cast<f16x2_t*>(p16 + j.dst + at) = f16x2_t{h16[0], h16[1]};
+      *reinterpret_cast<f16x2_t*>(p16 + jobs.copy_stride + j.dst + at) = f16x2_t{l16[0], l16[1]};
     }
   }
   if (status) {

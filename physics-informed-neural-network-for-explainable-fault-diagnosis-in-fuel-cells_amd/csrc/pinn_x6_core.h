@@ -50,7 +50,8 @@ constexpr int kSlabBytes = 3 * kCopyLds;    // x6: 3 copies (hi, mid, lo)
 struct Mat {
   unsigned off;      // 16-bit-element offset of (row 0, column 0) inside one copy
   int nrb_log;       // log2 of (output rows / 16): 16-row blocks per copy; a slab has kCopies << nrb_log 1-KB pieces
-  int kp_log = 0;    // log2 of the row stride: read only where the user's KP_LOG template argument is -1 (run-time choice of matrix)
+  int kp_log = 0;    // (round 1-2 layout: log2 of the row stride; no longer read)
+  int rows_log = -1; // log2 of the matrix's row count where a slab covers only part of the rows (wide nets); -1: the slab's rows are all of them
 };
 constexpr int clog2(int v) { return v <= 1 ? 0 : 1 + clog2(v >> 1); }
 
@@ -108,6 +109,7 @@ struct PipeT {
   unsigned copy_bytes;
   char* lds;                 // 2 x kSlab
   int par, wave;             // buffer holding the current slab; wave index (uniform)
+  int read_off;              // byte offset of the first row block this wave multiplies (0: all of them; the small-row-count kernels: its quarter)
   unsigned lane_row2, lane_kq8;  // 2 * (lane >> 2), 16 B * ((lane & 3) ^ swz(lane >> 2))
 
   // A piece is one buffer_load_dwordx4 ... lds: the resource and the piece's byte offset (soffset) are scalar, the
@@ -117,6 +119,7 @@ struct PipeT {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(packed), 0, 0x7FFFFFFF, 0x00020000);
     copy_bytes = __builtin_amdgcn_readfirstlane(copy_bytes_);      // (hipcc otherwise keeps it in a VGPR: waterfall loops)
     wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    read_off = 0;
     const int lane = tid & 63;
     lane_row2 = (unsigned)(lane >> 2) << 1;
     lane_kq8 = (unsigned)(((lane & 3) ^ swz(lane >> 2)) << 4);
@@ -129,10 +132,14 @@ struct PipeT {
     const int n = NCOPY << m.nrb_log;
     p = p < n ? p : p - n;
     asm volatile("" : "+s"(p));   // or hipcc precomputes every piece's offset outside the row loop (register pressure)
-    const int kp = KP_LOG >= 0 ? KP_LOG : m.kp_log;
-    const unsigned voff = (lane_row2 << kp) + lane_kq8;                    // bytes, per lane
+    // group-major copies (round 3): [K-group][row][32 elements] -- a slab is ONE contiguous run of rows x 64 B per copy, every
+    // 128-B line a piece touches is used whole.  (Row-major copies, rounds 1-2: a piece took 64 B out of each of 16 lines 512 B
+    // apart, so a slab pulled twice its bytes through the CU's 64 B/clk L1 fill path -- ~1000 cycles per 32-KB slab, found when the
+    // small-row-count kernels' 12-MFMA steps would not go below 1100 cycles.)
+    const int rs = m.rows_log >= 0 ? m.rows_log : m.nrb_log + 4;
+    const unsigned voff = (lane_row2 << 5) + lane_kq8;                     // bytes, per lane: row (lane >> 2) of the block, 64 B per row
     const int copy = p >> m.nrb_log, rb = p & ((1 << m.nrb_log) - 1);
-    const unsigned soff = (unsigned)copy * copy_bytes + 2u * (m.off + 32u * (unsigned)g + ((unsigned)(rb * 16) << kp));
+    const unsigned soff = (unsigned)copy * copy_bytes + 2u * (m.off + (((unsigned)g << rs) << 5) + (unsigned)rb * 512u);
     char* dst = lds + buf * kSlab + copy * kCopyLds + rb * 1024;
 #ifndef PINN_ABL_NOPIECE      // (ablation: what a slab step costs without its LDS-DMA instructions; results are garbage)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, voff, soff, 0, 0);
@@ -142,15 +149,15 @@ struct PipeT {
   // log2 of them): piece WAVES * J + wave is (copy, row block) = (static, static + wave), so the scalar offset is the
   // per-wave, per-matrix term mbase = wave_base<KP_LOG>(m) plus compile-time terms: 3 scalar instructions instead of 12.
   template <int KP_LOG>
-  __device__ __forceinline__ unsigned wave_base(const Mat& m) const { return 2u * m.off + (((unsigned)wave * 32u) << KP_LOG); }
+  __device__ __forceinline__ unsigned wave_base(const Mat& m) const { return 2u * m.off + (unsigned)wave * 1024u; }
   template <int KP_LOG, int WAVES, int NRB_LOG, int J>
   __device__ __forceinline__ void piece_s(unsigned mbase, int g, int buf) {
     constexpr int q = WAVES * J, copy = q >> NRB_LOG, rb0 = q & ((1 << NRB_LOG) - 1);
     static_assert(WAVES <= (1 << NRB_LOG) && copy < NCOPY, "piece_s: shape not separable");
     mbase = __builtin_amdgcn_readfirstlane(mbase);     // (wave-uniform by construction; hipcc does not always see it)
     asm volatile("" : "+s"(mbase));   // (or every piece's offset is precomputed outside the row loop: register pressure)
-    const unsigned voff = (lane_row2 << KP_LOG) + lane_kq8;
-    const unsigned soff = mbase + (unsigned)copy * copy_bytes + 64u * (unsigned)g + ((unsigned)(rb0 * 32) << KP_LOG);
+    const unsigned voff = (lane_row2 << 5) + lane_kq8;
+    const unsigned soff = mbase + (unsigned)copy * copy_bytes + ((unsigned)g << (NRB_LOG + 10)) + (unsigned)rb0 * 1024u;      // group stride: (16 << NRB_LOG) rows x 64 B
     char* dst = lds + buf * kSlab + wave * 1024 + copy * kCopyLds + rb0 * 1024;
 #ifndef PINN_ABL_NOPIECE
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, voff, soff, 0, 0);
@@ -165,7 +172,7 @@ struct PipeT {
       if (WAVES * j < (NCOPY << first.nrb_log)) piece<KP_LOG, WAVES>(first, 0, j, 0);
     __syncthreads();           // (drains the DMA: vmcnt(0) + barrier)
   }
-  __device__ __forceinline__ const char* cur() const { return lds + par * kSlab; }
+  __device__ __forceinline__ const char* cur() const { return lds + par * kSlab + read_off; }
   // end of a slab step: past the barrier every wave is done reading the current slab and the next one is complete.
   // kYoung = vector-memory operations this wave has issued AFTER its last LDS-DMA of the step (the training kernels'
   // stash stores, batched behind the step's last MFMA): vmcnt counts in issue order, so waiting for all but the
@@ -184,19 +191,6 @@ struct PipeT {
   }
 };
 using Pipe6 = PipeT<3>;
-
-// Small row counts (one wave per SIMD, fewer workgroups than CUs): a slab's multiply phase is ~0.4 us, the request for the
-// next slab goes out inside it, and the packed weights were written by another kernel a moment ago -- every slab is a first
-// touch for this XCD's L2, and all its workgroups walk the slab sequence in step, so every slab step waits out the miss.
-// The workgroups of an XCD (round-robin dispatch: blockIdx.x % 8) therefore split one sweep over the weight copies at kernel
-// start: one dword per 128-B line by LDS-DMA into a dummy (no registers to keep alive; retired by the first barrier).
-template <int kThreads>
-__device__ __forceinline__ void l2_warm(const void* base, unsigned bytes, char* lds_dummy) {
-  const unsigned n_wg = (gridDim.x + 7) / 8, r = blockIdx.x / 8;
-  const unsigned lines = bytes / 128;
-  for (unsigned i = r * kThreads + threadIdx.x; i < lines; i += n_wg * kThreads)
-    __builtin_amdgcn_global_load_lds((gptr_t)((const char*)base + (size_t)i * 128), (lptr_t)lds_dummy, 4, 0, 0);
-}
 
 // three bf16 fragments of the 8 fp32 values a lane holds in one 32-group: v = hi + mid + lo (exact)
 // K order inside a 32-group for the x6 kernels: B-fragment element jj = 2 r + b of lane group kq is feature
