@@ -810,13 +810,14 @@ static int train_grads_impl(const pinn_net_t* net, const float* d_params, const 
     // layer 0: dW0 = dpre_0 x^T
     g.P = a.dpre_h; g.Q = nullptr; g.OUT = H; g.IN = 8; g.dW = slabs + L.w0(); g.db = slabs + L.b0();
     g.s1 = nullptr; g.dvq = nullptr; g.s2 = nullptr; g.R = nullptr; g.dvr = nullptr;
-    const bool packed0 = net->precision == PINN_PREC_F32X6 && H <= 256;       // layer 0 from the packed operands too (below)
+    const bool packed0 = net->precision == PINN_PREC_F32X6;                   // layer 0 from the packed operands too (below)
     if (do_head && !packed0) { if ((rc = dispatch_wgrad(g, pick()))) return rc; }
     // every layer but the input one: split-bf16 products on the matrix cores for PINN_PREC_F32X6
     // operand split of the weight-gradient kernels: 0 = exact fp32 kernels; 3 = three bf16 parts, six products (x6); 4 = two fp16
     // parts under the common scale the X3 backward kernels measured (PINN_PREC_F32X6); 1 = bf16-mixed (wide nets)
-    if (net->precision == PINN_PREC_F32X6 && H <= 256) {
-      // packed stash: the chain kernels left every operand as fp16 fragments (pinn_x6_core.h), the row scales in the meta records
+    if (net->precision == PINN_PREC_F32X6) {
+      // packed stash: the chain kernels (fused nets) / layer kernels (wide nets) left every operand as fp16 fragments
+      // (pinn_x6_core.h), the row scales in the meta records
       WgradPArgs p{};
       p.meta = base + w.off_rowmeta; p.emax = (const unsigned*)(base + w.off_amax) + 1; p.qboost = row_scale_boost(a.drop, nh);
       p.t16 = w.t16; p.n_slices = w.n_slices; p.slab_stride = tot; p.q_log2 = 3;

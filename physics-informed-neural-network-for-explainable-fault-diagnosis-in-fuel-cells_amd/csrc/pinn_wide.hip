@@ -54,8 +54,13 @@ struct LayerArgs {
 
 // kNT accumulator blocks = 16 kNT output features per pass over the K-groups: 16 (256 features, half the input
 // re-reads and fragment splits) when OUT allows, else 8
-template <typename S, int EPI, int kNT>
+// kPk (PINN_PREC_F32X6): activations and d pre-activations travel between the kernels as the packed fragments of the fused
+// nets' stash (pinn_x6_core.h packed_ptr: per 16-row tile and 32-feature group 2 KB = parts hi, lo of 8 x the activation / of
+// the row-normalised gradient) instead of fp32: the consumer's B operand is a 16-B LDS read per part, not a split, and the
+// weight gradients run on wgrad_p_kernel.  EPI_TANH (the last variance layer) still writes fp32: only vector sums read it.
+template <typename S, int EPI, int kNT, bool kPk = false>
 __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a) {
+  static_assert(!kPk || S::kCopies == 2, "the packed form holds scheme X3's fragments");
   using Pipe = typename S::Pipe;
   using Frag = typename S::Frag;
   constexpr int kOB = 16 * kNT, kNrb = kNT == 16 ? 4 : 3;                 // features per pass; log2(16-row blocks)
@@ -104,10 +109,13 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
     fetch(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     Frag cur, nxt;
-    static_for<4>([&](auto rc) {
-      constexpr int r = decltype(rc)::value;
-      S::template split<r>(ring.read(0, 0, r) * bsc, ring.read(0, 1, r) * bsc, cur);
-    });
+    if constexpr (kPk) { cur.hi = ring.read_frag(0, 0); cur.lo = ring.read_frag(0, 1); }
+    else {
+      static_for<4>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        S::template split<r>(ring.read(0, 0, r) * bsc, ring.read(0, 1, r) * bsc, cur);
+      });
+    }
 #pragma unroll 1
     for (int ob = 0; ob < nob; ++ob) {
       f32x4 acc[kNT];
@@ -141,7 +149,9 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
         // chunks = tiles: the four register pairs of the next block, evenly spread
         auto vchunk = [&](auto cc) {
           constexpr int ci = decltype(cc)::value, every = kNT / 4;
-          if constexpr (ci % every == every - 1) {
+          if constexpr (kPk) {
+            if constexpr (ci == every - 1) { nxt.hi = ring.read_frag(gb & 1, 0); nxt.lo = ring.read_frag(gb & 1, 1); }
+          } else if constexpr (ci % every == every - 1) {
             constexpr int r = ci / every;
             S::template split<r>(ring.read(gb & 1, 0, r) * bsc, ring.read(gb & 1, 1, r) * bsc, nxt);
           }
@@ -152,12 +162,38 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
       }
       // ---- epilogue of these output features (X3: the accumulators carry 512 x the pre-activation)
       if constexpr (kAcc != 1.0f) {
-        const float back = EPI == EPI_BACKWARD ? unr * (1.0f / kWs) : kInvAcc;
+        const float back = EPI == EPI_BACKWARD ? (kPk ? 1.0f : unr) * (1.0f / kWs) : kInvAcc;
 #pragma unroll
         for (int t = 0; t < kNT; ++t) acc[t] = acc[t] * back;
       }
       float* out_tile = a.out + (t16 * a.OUT + ob * kOB + 4 * kq) * 16 + (lane & 15);
-      if (EPI == EPI_BACKWARD) {
+      if constexpr (EPI == EPI_BACKWARD && kPk) {
+        // act: 8 x the post-dropout activation as (hi, lo); the d pre-activations leave as (hi, lo) in the row's normalised units
+        const float scale = a.drop.mode != PINN_DROP_NONE ? a.drop.scale[a.layer] : 1.0f, inv_scale = 1.0f / (scale * kAct);
+        const float* hp = packed_ptr(const_cast<float*>(a.act), t16, a.OUT, lane) + (long long)ob * (kNT / 2) * 512;
+        float* dp = packed_ptr(a.out, t16, a.OUT, lane) + (long long)ob * (kNT / 2) * 512;
+        StashFrag fr[kNT / 2];
+#pragma unroll
+        for (int k = 0; k < kNT / 2; ++k) {
+          fr[k].hi = *reinterpret_cast<const u32x4*>(hp + 512 * k);
+          fr[k].lo = *reinterpret_cast<const u32x4*>(hp + 512 * k + 256);
+        }
+        static_for<kNT / 2>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          Frag out;
+          static_for<4>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const float h0 = unpack_act<0, r>(fr[k]), h1 = unpack_act<1, r>(fr[k]);
+            const float a0 = h0 * inv_scale, a1 = h1 * inv_scale;
+            const float g0 = acc[2 * k][r] * (scale * (1.0f - a0 * a0)), g1 = acc[2 * k + 1][r] * (scale * (1.0f - a1 * a1));
+            const float p0 = h0 != 0.0f ? g0 : 0.0f, p1 = h1 != 0.0f ? g1 : 0.0f;
+            amax = fmaxf(amax, fmaxf(fabsf(p0), fabsf(p1)) * unr);
+            S::template split<r>(p0, p1, out);
+          });
+          PINN_STASH_ST(reinterpret_cast<u32x4*>(dp + 512 * k), out.hi);
+          PINN_STASH_ST(reinterpret_cast<u32x4*>(dp + 512 * k + 256), out.lo);
+        });
+      } else if (EPI == EPI_BACKWARD) {
         const float scale = a.drop.mode != PINN_DROP_NONE ? a.drop.scale[a.layer] : 1.0f, inv_scale = 1.0f / scale;
         const float* hp = a.act + (t16 * a.OUT + ob * kOB + 4 * kq) * 16 + (lane & 15);
         f32x4 hl[kNT];
@@ -174,6 +210,24 @@ __global__ __launch_bounds__(kThreadsX, 2) void wide_layer_x6_kernel(LayerArgs a
           }
           store_block(out_tile, t, acc[t]);
         }
+      } else if constexpr (EPI == EPI_TANH_DROP && kPk) {
+        const LayerDrop ldr = layer_drop(a.drop, c.mode, a.layer);
+        float* op = packed_ptr(a.out, t16, a.OUT, lane) + (long long)ob * (kNT / 2) * 512;
+        static_for<kNT / 2>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          const unsigned keep = activate_pair_rt(acc[2 * k], acc[2 * k + 1], a.drop, c, ldr, a.layer, ob * (kNT / 2) + k);
+          Frag out;
+          static_for<4>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            // 8 x the activation (exact); a kept activation that is exactly 0 becomes the smallest fp16 subnormal ("dropped" is h == 0)
+            float h0 = acc[2 * k][r] * kAct, h1 = acc[2 * k + 1][r] * kAct;
+            h0 = (((keep >> r) & 1u) && h0 == 0.0f) ? 0x1p-24f : h0;
+            h1 = (((keep >> (4 + r)) & 1u) && h1 == 0.0f) ? 0x1p-24f : h1;
+            S::template split<r>(h0, h1, out);
+          });
+          PINN_STASH_ST(reinterpret_cast<u32x4*>(op + 512 * k), out.hi);
+          PINN_STASH_ST(reinterpret_cast<u32x4*>(op + 512 * k + 256), out.lo);
+        });
       } else if (EPI == EPI_TANH_DROP) {
         const LayerDrop ldr = layer_drop(a.drop, c.mode, a.layer);
 #pragma unroll
@@ -213,6 +267,8 @@ struct InputArgs {
   long long w0_off, b0_off;
   DropDev drop;
   unsigned pass;
+  int packed;               // PINN_PREC_F32X6: `out` as packed fragments (wide_layer_x6_kernel kPk)
+  float* stash_x;           // packed && training: the input rows as a packed group of their own (x / 16: layer 0's weight gradient), else nullptr
 };
 __global__ __launch_bounds__(256) void wide_input_kernel(InputArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane >> 4;
@@ -225,6 +281,18 @@ __global__ __launch_bounds__(256) void wide_input_kernel(InputArgs a) {
     // (injected masks are indexed by the LOCAL row: padding rows of the last tile read the last real row's words, never past the buffer)
     const RowCtx c{lane, kq, a.row_base + lrow, lrow < a.n_rows ? lrow : a.n_rows - 1, a.n_rows, a.pass, a.drop.mode};
     float* out_tile = a.out + (t16 * a.H + 4 * kq) * 16 + (lane & 15);
+    float* out_pk = packed_ptr(a.out, t16, a.H, lane);
+    if (a.stash_x) {
+      Frag2 fx;
+      static_for<4>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const float v = kq == 0 ? xa[r] : (kq == 1 ? xb[r] : 0.0f);
+        X3::split<r>(v * 0.0625f, 0.0f, fx);
+      });
+      float* xp = packed_ptr(a.stash_x, t16, 32, lane);
+      PINN_STASH_ST(reinterpret_cast<u32x4*>(xp), fx.hi);
+      PINN_STASH_ST(reinterpret_cast<u32x4*>(xp + 256), fx.lo);
+    }
     for (int fp = 0; fp < a.H / 32; ++fp) {
       f32x4 v[2];
 #pragma unroll
@@ -241,6 +309,19 @@ __global__ __launch_bounds__(256) void wide_input_kernel(InputArgs a) {
           v[b][r] = s;
         }
       const unsigned keep = activate_pair_rt(v[0], v[1], a.drop, c, ldr, 0, fp);
+      if (a.packed) {
+        Frag2 out;
+        static_for<4>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          float h0 = v[0][r] * X3::kActScale, h1 = v[1][r] * X3::kActScale;
+          h0 = (((keep >> r) & 1u) && h0 == 0.0f) ? 0x1p-24f : h0;
+          h1 = (((keep >> (4 + r)) & 1u) && h1 == 0.0f) ? 0x1p-24f : h1;
+          X3::split<r>(h0, h1, out);
+        });
+        PINN_STASH_ST(reinterpret_cast<u32x4*>(out_pk + 512 * fp), out.hi);
+        PINN_STASH_ST(reinterpret_cast<u32x4*>(out_pk + 512 * fp + 256), out.lo);
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         v[0][r] = stash_value(v[0][r], (keep >> r) & 1u);
@@ -266,20 +347,42 @@ struct HeadArgs {
   float* accum;             // modes 1, 2: [4][chunk rows]: u_eval, running mean of du, Welford m2 of du, sum logvar
   long long accum_stride;
   int pass;                 // mode 2: 0-based stochastic pass index
+  int packed;               // h as packed fragments
 };
+// <w_p, h> over this lane's share of the last hidden layer (all lanes of a row add up in sum_kq)
+__device__ __forceinline__ float head_dot(const float* h, long long t16, int H, int lane, const float* wp, int packed) {
+  const int kq = lane >> 4;
+  float up = 0.f;
+  if (packed) {
+    const float* hp = packed_ptr(const_cast<float*>(h), t16, H, lane);
+    for (int g = 0; g < H / 32; ++g) {
+      StashFrag fr;
+      fr.hi = *reinterpret_cast<const u32x4*>(hp + 512 * g);
+      fr.lo = *reinterpret_cast<const u32x4*>(hp + 512 * g + 256);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp + 32 * g + 4 * kq), w1 = *reinterpret_cast<const f32x4*>(wp + 32 * g + 16 + 4 * kq);
+      static_for<4>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        up = fmaf(w0[r], unpack_act<0, r>(fr) * (1.0f / X3::kActScale), up);
+        up = fmaf(w1[r], unpack_act<1, r>(fr) * (1.0f / X3::kActScale), up);
+      });
+    }
+  } else {
+    const float* hp = h + (t16 * H + 4 * kq) * 16 + (lane & 15);
+    for (int t = 0; t < H / 16; ++t) {
+      f32x4 hv;
+      load_block(hp, t, hv);
+      up = block_dot(hv, wp + t * 16, kq, up);
+    }
+  }
+  return up;
+}
 __global__ __launch_bounds__(256) void wide_heads_kernel(HeadArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane >> 4;
   const long long n_t16 = (a.n_rows + 127) / 128 * 8;
   for (long long t16 = (long long)blockIdx.x * 4 + wave; t16 < n_t16; t16 += (long long)gridDim.x * 4) {
     const long long lrow = t16 * 16 + (lane & 15);
-    const float* hp = a.h + (t16 * a.H + 4 * kq) * 16 + (lane & 15);
     const float* vp = a.v2 + (t16 * (a.H / 4) + 4 * kq) * 16 + (lane & 15);
-    float up = 0.f, zp = 0.f;
-    for (int t = 0; t < a.H / 16; ++t) {
-      f32x4 hv;
-      load_block(hp, t, hv);
-      up = block_dot(hv, a.params + a.wp_off + t * 16, kq, up);
-    }
+    float up = head_dot(a.h, t16, a.H, lane, a.params + a.wp_off, a.packed), zp = 0.f;
     for (int t = 0; t < a.H / 64; ++t) {
       f32x4 vv;
       load_block(vp, t, vv);
@@ -325,9 +428,11 @@ struct LossArgs {
   int H;
   long long wp_off, bp_off, wv2_off, bv2_off;
   unsigned* amax;            // running max |d pre-activation| of the call (this kernel: d pre_v2), or nullptr
+  int packed;                // PINN_PREC_F32X6: h and dv2 as packed fragments, dv2 in the rows' normalised units
+  unsigned* emax;            // packed: the call's largest max(|du|, |dz|) (zeroed before the launch): the row scales' reference
 };
 __global__ __launch_bounds__(256) void wide_loss_kernel(LossArgs a) {
-  float amax = 0.0f;
+  float amax = 0.0f, gmax = 0.0f;
   __shared__ double red[4][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane >> 4;
   const long long n_t16 = (a.n_rows + 127) / 128 * 8;
@@ -336,14 +441,8 @@ __global__ __launch_bounds__(256) void wide_loss_kernel(LossArgs a) {
   for (long long t16 = (long long)blockIdx.x * 4 + wave; t16 < n_t16; t16 += (long long)gridDim.x * 4) {
     const long long lrow = t16 * 16 + (lane & 15);
     const bool valid = lrow < a.n_rows;
-    const float* hp = a.h + (t16 * a.H + 4 * kq) * 16 + (lane & 15);
     const float* vp = a.v2 + (t16 * (a.H / 4) + 4 * kq) * 16 + (lane & 15);
-    float up = 0.f, zp = 0.f;
-    for (int t = 0; t < a.H / 16; ++t) {
-      f32x4 hv;
-      load_block(hp, t, hv);
-      up = block_dot(hv, a.params + a.wp_off + t * 16, kq, up);
-    }
+    float up = head_dot(a.h, t16, a.H, lane, a.params + a.wp_off, a.packed), zp = 0.f;
     for (int t = 0; t < a.H / 64; ++t) {
       f32x4 vv;
       load_block(vp, t, vv);
@@ -374,6 +473,30 @@ __global__ __launch_bounds__(256) void wide_loss_kernel(LossArgs a) {
       }
       if (lane < 16) { a.du[t16 * 16 + lane] = du; a.dz[t16 * 16 + lane] = dz; }
     }
+    if (a.packed) {
+      // the backward layers' first operand in the row's normalised units (norm = 2^(4 - e), max(|du|, |dz|) = m 2^e), as (hi, lo)
+      gmax = fmaxf(gmax, fmaxf(fabsf(du), fabsf(dz)));
+      const int e = grad_exponent(fmaxf(fabsf(du), fabsf(dz)), 4);
+      const float norm = ldexpf(1.0f, 4 - e), unr = ldexpf(1.0f, e - 4), dzn = dz * norm;
+      float* dpk = packed_ptr(a.dv2, t16, a.H / 4, lane);
+      for (int g = 0; g < a.H / 128; ++g) {
+        f32x4 v0, v1;
+        load_block(vp, 2 * g, v0);
+        load_block(vp, 2 * g + 1, v1);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.params + a.wv2_off + 32 * g + 4 * kq);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.params + a.wv2_off + 32 * g + 16 + 4 * kq);
+        Frag2 out;
+        static_for<4>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          const float p0 = w0[r] * dzn * (1.0f - v0[r] * v0[r]), p1 = w1[r] * dzn * (1.0f - v1[r] * v1[r]);
+          amax = fmaxf(amax, fmaxf(fabsf(p0), fabsf(p1)) * unr);
+          X3::split<r>(p0, p1, out);
+        });
+        PINN_STASH_ST(reinterpret_cast<u32x4*>(dpk + 512 * g), out.hi);
+        PINN_STASH_ST(reinterpret_cast<u32x4*>(dpk + 512 * g + 256), out.lo);
+      }
+      continue;
+    }
     float* dp = a.dv2 + (t16 * (a.H / 4) + 4 * kq) * 16 + (lane & 15);
     for (int t = 0; t < a.H / 64; ++t) {
       f32x4 vv;
@@ -392,6 +515,11 @@ __global__ __launch_bounds__(256) void wide_loss_kernel(LossArgs a) {
     for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
     if (lane == 0) atomicMax(a.amax, __float_as_uint(amax));
   }
+  if (a.packed && a.emax) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
+    if (lane == 0) atomicMax(a.emax, __float_as_uint(gmax));
+  }
   float terms[5] = {s_nll, s_abs, s_mse, s_du, s_dz};
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
@@ -407,6 +535,26 @@ __global__ __launch_bounds__(256) void wide_loss_kernel(LossArgs a) {
       for (int w = 0; w < 4; ++w) t += red[w][threadIdx.x];
     a.loss_part[(long long)blockIdx.x * 8 + threadIdx.x] = t;
   }
+}
+
+// The packed weight gradients' row records (pinn_x6_core.h RowMeta): per 16-row tile fp16 t_r = 2^(e_r - E + c), the two fp16 parts of
+// du_r norm_r, fp32 dz_r.  E comes from the loss kernel's maximum, complete when this launch starts.
+__global__ __launch_bounds__(256) void wide_rowmeta_kernel(const float* __restrict__ du, const float* __restrict__ dz, const unsigned* __restrict__ emax,
+                                                           int qboost, _Float16* __restrict__ meta, long long t16_total) {
+  const int E = grad_exponent(__uint_as_float(*emax), 4);
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= t16_total * 16) return;
+  const long long t16 = row >> 4;
+  const int n = (int)(row & 15);
+  const float d_u = du[row], d_z = dz[row];
+  const int e = grad_exponent(fmaxf(fabsf(d_u), fabsf(d_z)), E);
+  const float dun = d_u * ldexpf(1.0f, 4 - e);
+  _Float16* rec = meta + t16 * 128;
+  const _Float16 dh16 = (_Float16)dun;
+  rec[n] = (_Float16)ldexpf(1.0f, e - E + qboost);
+  rec[16 + n] = dh16;
+  rec[32 + n] = (_Float16)(dun - (float)dh16);
+  reinterpret_cast<float*>(rec)[32 + n] = d_z;
 }
 
 }  // namespace wide
@@ -427,6 +575,10 @@ static void launch_wide_layer(wide::LayerArgs la, int grid, hipStream_t st, int 
   } else if (EPI == wide::EPI_BACKWARD && precision == PINN_PREC_F32X6_G6) {
     if (la.OUT % 256 == 0) hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::X6, EPI, 16>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
     else hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::X6, EPI, 8>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
+  } else if (precision == PINN_PREC_F32X6) {      // packed activations / gradients between the kernels
+    la.packed += 3 * (size_t)la.copy_bytes;
+    if (la.OUT % 256 == 0) hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::X3, EPI, 16, true>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
+    else hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::X3, EPI, 8, true>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
   } else {
     la.packed += 3 * (size_t)la.copy_bytes;
     if (la.OUT % 256 == 0) hipLaunchKernelGGL((wide::wide_layer_x6_kernel<x6::X3, EPI, 16>), dim3(grid), dim3(x6::kThreadsX), 0, st, la);
@@ -455,6 +607,7 @@ int launch_forward_wide(const pinn_net_t* net, const FwdArgs& fa, bool mc, void*
   float* v1 = bufB + (size_t)kWideChunk * H; float* v2 = v1 + (size_t)kWideChunk * (H / 2);
   float* accum = v2 + (size_t)kWideChunk * (H / 4);
   const int cus = wide_cus();
+  const int pk = net->precision == PINN_PREC_F32X6;      // activations between the kernels as packed fragments
   const int n_passes = mc ? fa.n_passes : 0;
   for (long long r0 = 0; r0 < fa.n_rows; r0 += kWideChunk) {
     const long long n = fa.n_rows - r0 < kWideChunk ? fa.n_rows - r0 : kWideChunk;
@@ -469,7 +622,7 @@ int launch_forward_wide(const pinn_net_t* net, const FwdArgs& fa, bool mc, void*
         d.bits = fa.drop.bits + ((long long)p * fa.n_rows + r0) * d.words;
         p = 0u;
       }
-      InputArgs ia{fa.params, fa.x + r0 * 8, bufA, n, d.row_offset + r0, H, L.w0(), L.b0(), d, p};
+      InputArgs ia{fa.params, fa.x + r0 * 8, bufA, n, d.row_offset + r0, H, L.w0(), L.b0(), d, p, pk, nullptr};
       hipLaunchKernelGGL(wide_input_kernel, dim3(grid_s), dim3(256), 0, st, ia);
       float* cur = bufA; float* nxt = bufB;
       LayerArgs la{};
@@ -487,7 +640,7 @@ int launch_forward_wide(const pinn_net_t* net, const FwdArgs& fa, bool mc, void*
       la.bias_off = L.bv1(); la.layer = nh + 1;
       launch_wide_layer<EPI_TANH>(la, grid_l, st, net->precision);
       HeadArgs ha{fa.params, cur, v2, n, H, L.wp(), L.bp(), L.wv2(), L.bv2(), mc ? (pass < 0 ? 1 : 2) : 0,
-                  fa.o0 + r0, mc ? nullptr : fa.o1 + r0, accum, kWideChunk, pass < 0 ? 0 : pass};
+                  fa.o0 + r0, mc ? nullptr : fa.o1 + r0, accum, kWideChunk, pass < 0 ? 0 : pass, pk};
       hipLaunchKernelGGL(wide_heads_kernel, dim3(grid_s), dim3(256), 0, st, ha);
       if (!mc) break;
     }
@@ -518,7 +671,8 @@ int launch_train_chain_wide(const pinn_net_t* net, const float* d_params, const 
   float* dh = (float*)b.dpre_h; float* dv1 = (float*)b.dpre_v1; float* dv2 = (float*)b.dpre_v2;
   auto log2i = [](int v) { return 31 - __builtin_clz((unsigned)v); };
 
-  InputArgs ia{d_params, d_x, sh, n_rows, drop.row_offset, H, L.w0(), L.b0(), drop, 0u};
+  const int pk = net->precision == PINN_PREC_F32X6;      // packed stash: the weight gradients run on wgrad_p_kernel (pinn_train.hip)
+  InputArgs ia{d_params, d_x, sh, n_rows, drop.row_offset, H, L.w0(), L.b0(), drop, 0u, pk, pk ? (float*)b.stash_x : nullptr};
   hipLaunchKernelGGL(wide_input_kernel, dim3(grid_s), dim3(256), 0, st, ia);
   LayerArgs la{};
   la.params = d_params; la.packed = packed; la.copy_bytes = copy_bytes; la.n_rows = n_rows; la.row_base = drop.row_offset; la.drop = drop; la.pass = 0;
@@ -538,12 +692,14 @@ int launch_train_chain_wide(const pinn_net_t* net, const float* d_params, const 
   const int grid_loss = (int)(t4 < 1024 ? (t4 < 1 ? 1 : t4) : 1024);
   const bool x3_grads = net->precision == PINN_PREC_F32X6;          // gradients in scheme X3: the call's largest |d pre| is recorded
   if (x3_grads) {
-    hipError_t em = hipMemsetAsync(b.amax, 0, sizeof(unsigned), st);
+    hipError_t em = hipMemsetAsync(b.amax, 0, 2 * sizeof(unsigned), st);      // amax and emax (TrainBuffers: consecutive words)
     if (em != hipSuccess) return (int)em;
   }
   LossArgs lo{d_params, sh + (nh - 1) * hs, sv2, dv2, d_y, b.du, b.dz, b.loss_part, n_rows, n_global, H, L.wp(), L.bp(), L.wv2(), L.bv2(),
-              x3_grads ? b.amax : nullptr};
+              x3_grads ? b.amax : nullptr, pk, pk ? b.emax : nullptr};
   hipLaunchKernelGGL(wide_loss_kernel, dim3(grid_loss), dim3(256), 0, st, lo);
+  if (pk) hipLaunchKernelGGL(wide_rowmeta_kernel, dim3((unsigned)((b.t16 * 16 + 255) / 256)), dim3(256), 0, st, b.du, b.dz, b.emax, b.qboost,
+                             (_Float16*)b.rowmeta, b.t16);
   la.du = b.du; la.dz = b.dz; la.amax = b.amax;
   *grid_out = grid_loss;
 

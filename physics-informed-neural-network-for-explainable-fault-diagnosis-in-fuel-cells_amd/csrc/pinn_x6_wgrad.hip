@@ -765,7 +765,21 @@ __device__ __forceinline__ void wgrad_p_body(const WgradPArgs& a, const int slic
 template <int TI, int TJ, int WI, int WJ, bool kVQ, bool kVR, int S>
 __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_p_kernel(WgradPArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char ring[];
-  wgrad_p_body<TI, TJ, WI, WJ, kVQ, kVR, S>(a, blockIdx.x, blockIdx.y, blockIdx.z, ring);
+  int slice = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (gridDim.y * gridDim.z > 1 && (gridDim.x & 7) == 0) {
+    // A gradient of several blocks (the wide nets: 4 x 4 blocks of 256 x 256 at H = 1024): every block of a block ROW reads the
+    // same P tiles, and in launch order (x fastest) the workgroups resident at one time were the slices of ONE block -- each
+    // operand came from HBM once per block, four times in all (29 GB, 8.5 ms at 262 144 rows).  Workgroups are handed to the
+    // XCDs round-robin by their linear index: re-number them so that an XCD holds, side by side, the blocks bz = 0 .. nz - 1 of
+    // the same (slice, block row) -- they stream the same P tiles at the same pace, three of four reads hit that XCD's L2.
+    const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = id & 7u, k = id >> 3, per_xcd = gridDim.x >> 3;
+    bz = (int)(k % gridDim.z);
+    const unsigned r = k / gridDim.z;
+    slice = (int)((r % per_xcd) * 8u + xcd);
+    by = (int)(r / per_xcd);
+  }
+  wgrad_p_body<TI, TJ, WI, WJ, kVQ, kVR, S>(a, slice, by, bz, ring);
 }
 
 // Small row counts (the reference's own: 1e3 .. 3e4 rows), H = 256: every layer's gradient in ONE launch.  Five launches
@@ -874,20 +888,21 @@ int dispatch_wgrad_p(const WgradPArgs& a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int to = a.OUT / 32, ti = a.IN / 32;
   if (!a.P || !a.Q || !a.meta || !a.emax || a.IN % 32 || a.OUT % 32) return PINN_E_ARG;
-  if (a.dvq) {                     // variance head layer 0 (+ the predict head's weight): H = 256 / 128
-    if (to == 4 && ti == 8) return launch_p<2, 4, 2, 2, true>(a, st);
-    if (to == 2 && ti == 4) return launch_p<1, 2, 2, 2, true>(a, st);
+  // (the wide nets, H = 512 / 1024 / 2048: the same kernels over blocks of the gradient, blockIdx.y / z)
+  if (a.dvq) {                     // variance head layer 0 (+ the predict head's weight)
+    if (to == 2 && ti == 4) return launch_p<1, 2, 2, 2, true>(a, st);                   // H = 128
+    if (to % 4 == 0 && ti % 8 == 0) return launch_p<2, 4, 2, 2, true>(a, st);           // H = 256: one block of 128 x 256; wide: several
     return PINN_E_ARCH;
   }
-  if (a.dvr) {                     // variance head layer 1 (+ the head's last weight, fp32 operands): H = 256 / 128
+  if (a.dvr) {                     // variance head layer 1 (+ the head's last weight, fp32 operands)
     if (!a.R || !a.s2) return PINN_E_ARG;
-    if (to == 2 && ti == 4) return launch_p<1, 2, 2, 2, false, true>(a, st);
-    if (to == 1 && ti == 2) return launch_p<1, 1, 1, 2, false, true>(a, st);
+    if (to == 1 && ti == 2) return launch_p<1, 1, 1, 2, false, true>(a, st);           // H = 128
+    if (to % 2 == 0 && ti % 4 == 0) return launch_p<1, 2, 2, 2, false, true>(a, st);    // blocks of 64 x 128
     return PINN_E_ARCH;
   }
-  if (to == 8 && ti == 8) return launch_p<4, 4, 2, 2>(a, st);
-  if (to == 4 && ti == 4) return launch_p<2, 2, 2, 2>(a, st);
-  if (to == 8 && ti == 1) return launch_p<2, 1, 4, 1>(a, st);      // layer 0 (Q = the packed input rows): H = 256 / 128
+  if (to % 8 == 0 && ti % 8 == 0) return launch_p<4, 4, 2, 2>(a, st);                    // blocks of 256 x 256
+  if (to == 4 && ti == 4) return launch_p<2, 2, 2, 2>(a, st);                           // H = 128
+  if (to % 8 == 0 && ti == 1) return launch_p<2, 1, 4, 1>(a, st);                       // layer 0 (Q = the packed input rows)
   if (to == 4 && ti == 1) return launch_p<1, 1, 4, 1>(a, st);
   return PINN_E_ARCH;
 }
