@@ -605,18 +605,46 @@ __device__ __forceinline__ void layer_x6(f32x4 (&acc)[NTOUT], typename S::Pipe& 
 }
 
 // small parameter vectors -> LDS (all threads).  The biases of the matrix layers carry the accumulator scale of scheme S.
+// Two phases: every global load of the thread is issued before the first LDS store.  Written as one loop per vector (load,
+// store, next vector) the compiler waited out an L2 round trip per loop -- twelve in a row, 5 800 cycles = 2.7 us before a
+// kernel's first slab (tools/q_stamps.py), a fifteenth of a training kernel at the reference's row counts.
 template <typename S, int kThreads>
 __device__ __forceinline__ void fill_small(float* small, float* w0t, const float* __restrict__ params, const ParamLayout& L) {
   const SmallLayout SL{L.H, L.nh};
   const int Hh = L.H, tid = threadIdx.x;
-  for (int i = tid; i < Hh; i += kThreads) small[SL.b(0) + i] = params[L.b(0) + i];
-  for (int l = 1; l < L.nh; ++l)
-    for (int i = tid; i < Hh; i += kThreads) small[SL.b(l) + i] = params[L.b(l) + i] * S::kAccScale;
-  for (int i = tid; i < Hh; i += kThreads) small[SL.wp() + i] = params[L.wp() + i];
-  for (int i = tid; i < Hh / 2; i += kThreads) small[SL.bv0() + i] = params[L.bv0() + i] * S::kAccScale;
-  for (int i = tid; i < Hh / 4; i += kThreads) { small[SL.bv1() + i] = params[L.bv1() + i] * S::kAccScale; small[SL.wv2() + i] = params[L.wv2() + i]; }
-  if (tid == 0) { small[SL.bp()] = params[L.bp()]; small[SL.bv2()] = params[L.bv2()]; }
-  for (int e = tid; e < Hh * 8; e += kThreads) w0t[(e & 7) * kW0Stride + (e >> 3)] = params[L.w0() + e];
+  constexpr int kMaxH = 256, kPer = (kMaxH + kThreads - 1) / kThreads;        // elements of an H-vector per thread
+  constexpr int kW0 = (8 * kMaxH + kThreads - 1) / kThreads, kMaxLayers = 8;
+  float vb[kMaxLayers][kPer], vwp[kPer], vbv0[kPer], vbv1[kPer], vwv2[kPer], vw0[kW0], vbp = 0.f, vbv2 = 0.f;
+#pragma unroll
+  for (int l = 0; l < kMaxLayers; ++l)
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) { const int i = tid + k * kThreads; vb[l][k] = (l < L.nh && i < Hh) ? params[L.b(l) + i] : 0.f; }
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int i = tid + k * kThreads;
+    vwp[k] = i < Hh ? params[L.wp() + i] : 0.f;
+    vbv0[k] = i < Hh / 2 ? params[L.bv0() + i] : 0.f;
+    vbv1[k] = i < Hh / 4 ? params[L.bv1() + i] : 0.f;
+    vwv2[k] = i < Hh / 4 ? params[L.wv2() + i] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < kW0; ++k) { const int e = tid + k * kThreads; vw0[k] = e < Hh * 8 ? params[L.w0() + e] : 0.f; }
+  if (tid == 0) { vbp = params[L.bp()]; vbv2 = params[L.bv2()]; }
+  // ---- stores
+#pragma unroll
+  for (int l = 0; l < kMaxLayers; ++l)
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) { const int i = tid + k * kThreads; if (l < L.nh && i < Hh) small[SL.b(l) + i] = l == 0 ? vb[l][k] : vb[l][k] * S::kAccScale; }
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int i = tid + k * kThreads;
+    if (i < Hh) small[SL.wp() + i] = vwp[k];
+    if (i < Hh / 2) small[SL.bv0() + i] = vbv0[k] * S::kAccScale;
+    if (i < Hh / 4) { small[SL.bv1() + i] = vbv1[k] * S::kAccScale; small[SL.wv2() + i] = vwv2[k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < kW0; ++k) { const int e = tid + k * kThreads; if (e < Hh * 8) w0t[(e & 7) * kW0Stride + (e >> 3)] = vw0[k]; }
+  if (tid == 0) { small[SL.bp()] = vbp; small[SL.bv2()] = vbv2; }
   __syncthreads();
 }
 

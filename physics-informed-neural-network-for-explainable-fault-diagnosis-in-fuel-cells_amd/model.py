@@ -519,7 +519,7 @@ class PhysicsInformedNN():
             ls = _dp.allreduce_sums(sums.clone(), self._group).cpu().numpy()      # fp64, only when a line is printed
             lr_next = 0.01 * 0.8 ** ((epoch + 1) // 1000)
             self._log(f' {epoch:5d}  | {(ls[0] + 0.01 * ls[1]) / n_norm:10.3e} | {ls[2] / n_norm:10.3e} | {lr_next:8.1e}')
-        replay = (self.use_graph and nIter >= 2 and len(batches) == 1 and batches[0][:2] == (0, n) and n > 0 and not _dp._active(self._group)
+        replay = (self.use_graph and nIter >= max(2, self.graph_min_steps) and len(batches) == 1 and batches[0][:2] == (0, n) and n > 0 and not _dp._active(self._group)
                   and self.dnn.hidden <= 256)
         for epoch in range(nIter):
             lr = 0.01 * 0.8 ** (epoch // 1000)
@@ -595,6 +595,7 @@ class PhysicsInformedNN():
         self.last_loss = float(loss[0].item()) if nIter > 0 else None
 
     graph_chunk = 8                 # train_dnn steps per graph launch in long replayed calls
+    graph_min_steps = 200           # shorter calls launch their steps one by one: a capture costs ~0.5 ms, a replayed step is no faster
     stage_run_max_rows = 32768      # <= _lib.STAGE_RUN_MAX_ROWS; larger series iterate the multi-workgroup kernels
     _lambda_log_view = None
 

@@ -109,6 +109,7 @@ def test_train_dnn_three_steps_golden():
     m = _model_from_golden(g, g["x"], g["y"], sx, sy, prefix="w0.")
     per_step = [[unpack_mask(g["mask%d_s%d" % (l, s)], 128 if l < 3 else 64) for l in range(4)] for s in range(3)]
     m.dnn.inject_masks(hh.pack_mask_bits(per_step))
+    m.graph_min_steps = 0              # through the replayed-graph path (the default only for calls of >= 200 steps)
     m.train_dnn(3)
     sd = m.dnn.state_dict()
     for n in O.param_names(3):
@@ -309,6 +310,7 @@ def test_train_dnn_philox_masks_vs_oracle(batch_size):
     names = O.param_names(3)
     sd = m.dnn.state_dict()
     P = [sd[n].detach().cpu().clone() for n in names]
+    m.graph_min_steps = 0              # the full-batch case runs through the replayed graph
     m.train_dnn(epochs, batch_size=batch_size)
     bounds = [(0, N)] if batch_size is None else [(s, min(N, s + batch_size)) for s in range(0, N, batch_size)]
     mask_fn = lambda step, s, e: (O.philox_masks_for_net(seed, step, s, e - s, H, 3, [0.2] * 4), [0.2] * 4)
@@ -343,6 +345,7 @@ def test_train_dnn_graph_replay_is_bit_identical(precision, H):
         m.verbose = False
         m.use_graph = use_graph
         m.graph_chunk = 2                  # long calls replay several steps per graph launch: exercised here at 9 steps
+        m.graph_min_steps = 0
         if bits is not None:
             m.dnn.inject_masks(bits)
         m.train_dnn(steps)
