@@ -266,7 +266,9 @@ struct StageDef {
 };
 
 // bc1 = 1 - 0.9^step, bc2 = 1 - 0.999^step (torch computes them in double)
-__device__ void lambda_step_body(int stage, const double* sums, double inv_n, float vn_scale, float lr, double bc1, double bc2, float* lambdas,
+// (forceinline: in the persistent kernel `stage` is a compile-time constant per instantiation, so the parameter table, the
+//  loops over it and the gradient arrays dissolve into registers; as a called function they lived in scratch)
+__device__ __forceinline__ void lambda_step_body(int stage, const double* sums, double inv_n, float vn_scale, float lr, double bc1, double bc2, float* lambdas,
                                  float* adam, float* loss_out) {
   StageDef d;
   float g[5];
@@ -318,7 +320,9 @@ __device__ void lambda_step_body(int stage, const double* sums, double inv_n, fl
   // torch.optim.Adam (single tensor path): bias corrections in double, tensor math in float32
   const float step_size = (float)((double)lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
-  for (int k = 0; k < d.n; ++k) {
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    if (k >= d.n) break;
     const int id = d.idx[k];
     float p = lambdas[id];
     if (has_grad[k]) {          // a parameter whose .grad is None is skipped entirely
@@ -465,23 +469,28 @@ __device__ __forceinline__ void stage_terms(const float (&c)[kCacheFloats], cons
   }
 }
 
+// One instantiation per stage kind: with the flags a constant only that stage's sums, cache columns and parameters exist (as
+// one kernel with run-time flags it held all 32 accumulators per thread: 128 registers, 28 of them spilled, 144 B of scratch
+// per lane touched in every iteration).
+template <unsigned kFlags>
 __global__ __launch_bounds__(kStageThreads) void stage_run_kernel(
-    int stage, unsigned flags, const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ y, AffineDev aff,
+    int stage_rt, const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ y, AffineDev aff,
     long long n_rows, double lr0, double gamma, int lr_step, int first_epoch, int n_iters, float* __restrict__ lambdas,
     float* __restrict__ adam, float* __restrict__ loss_out, float* __restrict__ log, int log_every, double* __restrict__ sums_out,
     float* __restrict__ work) {
   __shared__ double red[kStageThreads / 64][PINN_NSUMS];
   __shared__ double sums[PINN_NSUMS];
   __shared__ float lam_s[PINN_NLAMBDA], adam_s[2 * PINN_NLAMBDA], loss_s[2];
+  constexpr unsigned flags = kFlags;
+  // (the voltage stage has two variants, chosen at run time; the others are fixed by the flags)
+  const int stage = kFlags == PINN_RES_T ? PINN_STAGE_THERMAL : (kFlags == PINN_RES_H ? PINN_STAGE_HYDROGEN : (kFlags == PINN_RES_O ? PINN_STAGE_OXYGEN
+                    : (stage_rt == PINN_STAGE_LAMBDA_F ? PINN_STAGE_LAMBDA_F : PINN_STAGE_LAMBDA_PM)));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < PINN_NLAMBDA) lam_s[tid] = lambdas[tid];
   if (tid < 2 * PINN_NLAMBDA) adam_s[tid] = adam[tid];
   // the sums this stage reads: a contiguous range of the enum
-  int s_lo, s_hi;
-  if (flags & PINN_RES_V) { s_lo = PINN_S_FV2; s_hi = PINN_S_YU2 + 1; }
-  else if (flags & PINN_RES_T) { s_lo = PINN_S_FT2; s_hi = PINN_S_FT_ABS + 1; }
-  else if (flags & PINN_RES_H) { s_lo = PINN_S_FH2; s_hi = PINN_S_TGTH + 1; }
-  else { s_lo = PINN_S_FO2; s_hi = PINN_S_TGTO + 1; }
+  constexpr int s_lo = (kFlags & PINN_RES_V) ? PINN_S_FV2 : ((kFlags & PINN_RES_T) ? PINN_S_FT2 : ((kFlags & PINN_RES_H) ? PINN_S_FH2 : PINN_S_FO2));
+  constexpr int s_hi = 1 + ((kFlags & PINN_RES_V) ? PINN_S_YU2 : ((kFlags & PINN_RES_T) ? PINN_S_FT_ABS : ((kFlags & PINN_RES_H) ? PINN_S_TGTH : PINN_S_TGTO)));
   if (tid < PINN_NSUMS) sums[tid] = 0.0;
   {   // parameter-independent part of every row, once
     const LamDev L0 = load_lambdas(lambdas);
@@ -493,7 +502,7 @@ __global__ __launch_bounds__(kStageThreads) void stage_run_kernel(
     }
   }
   __syncthreads();
-  const int n_cached = (flags & PINN_RES_V) ? 6 : ((flags & PINN_RES_T) ? 4 : 2);
+  constexpr int n_cached = (kFlags & PINN_RES_V) ? 6 : ((kFlags & PINN_RES_T) ? 4 : 2);
   const double inv_n = 1.0 / (double)n_rows;
   // thread 0's optimizer state: beta^step as running products (pow() once), the StepLR rate recomputed at its edges
   double b1p = pow(0.9, (double)first_epoch), b2p = pow(0.999, (double)first_epoch);
@@ -504,18 +513,20 @@ __global__ __launch_bounds__(kStageThreads) void stage_run_kernel(
     float acc[PINN_NSUMS];
 #pragma unroll
     for (int s = 0; s < PINN_NSUMS; ++s) acc[s] = 0.0f;
-    // four rows per trip: their (L2) loads are all in flight before the first is used
-    for (long long row0 = tid; row0 < n_rows; row0 += 4 * kStageThreads) {
-      float c[4][kCacheFloats];
+    // several rows per trip: their (L2) loads are all in flight before the first is used (the voltage stage, six cached floats
+    // and nine sums per row, has registers for two; the others for four)
+    constexpr int kTrip = (kFlags & PINN_RES_V) ? 2 : 4;
+    for (long long row0 = tid; row0 < n_rows; row0 += kTrip * kStageThreads) {
+      float c[kTrip][kCacheFloats];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < kTrip; ++q) {
         const long long row = row0 + q * kStageThreads;
         const long long rr = row < n_rows ? row : row0;
 #pragma unroll
         for (int k = 0; k < kCacheFloats; ++k) c[q][k] = k < n_cached ? work[k * n_rows + rr] : 0.0f;
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < kTrip; ++q)
         if (row0 + q * kStageThreads < n_rows) stage_terms(c[q], aff, L, flags, acc);
     }
 #pragma unroll
@@ -732,8 +743,14 @@ extern "C" int pinn_lambda_stage_run(int stage, unsigned flags, const float* d_x
   AffineDev a;
   for (int c = 0; c < 8; ++c) { a.x_min[c] = aff->x_min[c]; a.x_scale[c] = aff->x_scale[c]; }
   a.y_min = aff->y_min; a.y_scale = aff->y_scale; a.vn_scale = aff->vn_scale; a.vn_min = aff->vn_min;
-  hipLaunchKernelGGL(stage_run_kernel, dim3(1), dim3(kStageThreads), 0, (hipStream_t)stream, stage, flags, d_x, d_u, d_y, a, n_rows, lr0, gamma,
-                     lr_step, first_epoch, n_iters, d_lambda, d_adam, d_loss, d_log, log_every, d_sums, (float*)d_work);
+#define PINN_STAGE_LAUNCH(F)                                                                                                          \
+  hipLaunchKernelGGL((stage_run_kernel<F>), dim3(1), dim3(kStageThreads), 0, (hipStream_t)stream, stage, d_x, d_u, d_y, a, n_rows, lr0, gamma, \
+                     lr_step, first_epoch, n_iters, d_lambda, d_adam, d_loss, d_log, log_every, d_sums, (float*)d_work)
+  if (flags == PINN_RES_V) PINN_STAGE_LAUNCH(PINN_RES_V);
+  else if (flags == PINN_RES_T) PINN_STAGE_LAUNCH(PINN_RES_T);
+  else if (flags == PINN_RES_H) PINN_STAGE_LAUNCH(PINN_RES_H);
+  else PINN_STAGE_LAUNCH(PINN_RES_O);
+#undef PINN_STAGE_LAUNCH
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PINN_OK : (int)e;
 }
