@@ -571,7 +571,12 @@ static Workspace plan_workspace(const pinn_net_t* net, long long n_rows) {
   // (fan_out below), 320 workgroups in all; PINN_PREC_F32X6 at H = 256 runs them as ONE launch of 128 x 128 tiles
   // (wgrad_p_multi_kernel): 32 slices, ~450 workgroups
   const bool one_launch = net->precision == PINN_PREC_F32X6 && H == 256 && nh - 1 + 3 <= kMaxWgradProblems;
-  const long long cap = w.t16 < kFanOutT16 ? (one_launch ? 32 : 64) : kMaxSlices;
+#ifdef PINN_ABL_MULTI_NS
+  constexpr long long kMultiSlices = PINN_ABL_MULTI_NS;
+#else
+  constexpr long long kMultiSlices = 32;
+#endif
+  const long long cap = w.t16 < kFanOutT16 ? (one_launch ? kMultiSlices : 64) : kMaxSlices;
   w.n_slices = (int)(t32 < cap ? (t32 < 1 ? 1 : t32) : cap);
   ParamLayout L{(int)H, (int)nh};
   w.off_slabs = take((size_t)w.n_slices * L.total() * 4);

@@ -805,7 +805,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_p_multi_kernel(WgradPMulti m) {
 }
 
 int launch_wgrad_p_multi(const WgradPMulti& m_in, hipStream_t st) {
+#ifdef PINN_ABL_MULTI_S
+  constexpr int S = PINN_ABL_MULTI_S;
+#else
   constexpr int S = 3;
+#endif
   WgradPMulti m = m_in;
   int nb = 0;
   size_t lds = 0;
@@ -827,7 +831,7 @@ int launch_wgrad_p_multi(const WgradPMulti& m_in, hipStream_t st) {
   auto kfn = wgrad_p_multi_kernel<S>;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * (9 * 2048 + 256)));
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S * (9 * 2048 + 256)));
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
