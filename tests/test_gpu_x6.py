@@ -96,7 +96,11 @@ def _check_grads(got_flat, want_list, H, nh, rtol, atol_scale=1e-6):
 
 @pytest.mark.parametrize("prec", [2, 3])
 @pytest.mark.parametrize("H,nh,N,mode", [(256, 3, 1000, 1), (128, 3, 333, 1), (256, 2, 129, 0), (128, 4, 4096, 1), (256, 1, 64, 1),
-                                         (128, 1, 200, 1), (256, 3, 17001, 1), (128, 2, 20000, 1)])
+                                         (128, 1, 200, 1), (256, 3, 17001, 1), (128, 2, 20000, 1),
+                                         # H = 256 chooses its forward kernel by row count: four waves per 16-row tile up to 8192 rows
+                                         # (nh = 5 and the ragged 8192 + 1 boundary here), one wave per tile in 64-row workgroups up to
+                                         # 16 384, 128-row workgroups beyond
+                                         (256, 5, 300, 1), (256, 3, 8192, 1), (256, 3, 8193, 1), (256, 4, 12000, 1)])
 def test_train_grads_x6_vs_oracle_autograd(lib, H, nh, N, mode, prec):
     """Training step of the split-operand family (forward + NLL kernel, backward kernel, weight-gradient kernels; prec 2 =
     PINN_PREC_F32X6: two fp16 parts / three products everywhere; prec 3 = PINN_PREC_F32X6_G6: gradients from three bf16
@@ -229,7 +233,7 @@ def test_mc_dropout_wide(lib):
     np.testing.assert_allclose(o[2], np.asarray(eu).reshape(-1), rtol=1e-3, atol=2e-6)      # atol: the fp32 forward noise of u_t itself
 
 
-@pytest.mark.parametrize("H,nh,N,mode", [(512, 2, 300, 1), (1024, 4, 200, 1), (512, 1, 129, 0)])
+@pytest.mark.parametrize("H,nh,N,mode", [(512, 2, 300, 1), (1024, 4, 200, 1), (512, 1, 129, 0), (2048, 2, 70, 1)])
 def test_train_grads_wide_vs_oracle_autograd(lib, H, nh, N, mode):
     """Training step of a wide net (layer-by-layer x6 kernels + blocked weight-gradient kernels) against torch autograd
     on the oracle: loss and all 14 gradient tensors at the tolerances of the fused kernels."""
