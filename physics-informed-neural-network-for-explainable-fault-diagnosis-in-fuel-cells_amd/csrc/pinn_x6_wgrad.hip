@@ -895,6 +895,7 @@ int dispatch_wgrad_p(const WgradPArgs& a, void* stream) {
   // (the wide nets, H = 512 / 1024 / 2048: the same kernels over blocks of the gradient, blockIdx.y / z)
   if (a.dvq) {                     // variance head layer 0 (+ the predict head's weight)
     if (to == 2 && ti == 4) return launch_p<1, 2, 2, 2, true>(a, st);                   // H = 128
+    if (to % 8 == 0 && ti % 8 == 0) return launch_p<4, 4, 2, 2, true>(a, st);           // wide nets: blocks of 256 x 256 (7.2 -> 7.0 ms at H = 1024)
     if (to % 4 == 0 && ti % 8 == 0) return launch_p<2, 4, 2, 2, true>(a, st);           // H = 256: one block of 128 x 256; wide: several
     return PINN_E_ARCH;
   }
