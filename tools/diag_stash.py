@@ -68,9 +68,6 @@ for name, idx, F, layers in (("h", 0, H, nh), ("v1", 1, H // 2, 1)):
 for name, idx, F, layers in (("dpre_h", 3, H, nh), ("dpre_v1", 4, H // 2, 1), ("dpre_v2", 5, H // 4, 1)):
     ref = tiled_fp32(w0, offs[idx], F, layers)
     for l in range(layers):
-        if name == "dpre_h" and l == 0:
-            got = tiled_fp32(w2, offs[idx], F, layers)[0]
-            d = np.abs(got[:N] - ref[0][:N]); print("dpre_h layer 0 (fp32 both): max err %.3e of max %.3e" % (d.max(), np.abs(ref[0][:N]).max())); continue
         got = packed(w2, offs[idx], F, layers)[0][l][:N]
         r = ref[l][:N].astype(np.float64)
         # per-row power-of-two scale: recover from the largest element
@@ -85,30 +82,13 @@ offs_p, total = __import__("pinn_amd").layout.param_offsets(8, H, nh)
 for (n, shape, off) in offs_p:
     k = int(np.prod(shape)); a, b = g2[off:off + k], g0[off:off + k]
     print("%-24s max |f32x6 - fp32| / max = %.2e" % (n, np.abs(a - b).max() / (np.abs(b).max() + 1e-30)))
-# ---- layer 0 in detail
-ref0 = tiled_fp32(w0, offs[3], H, nh)[0][:N].astype(np.float64)
-got0 = tiled_fp32(w2, offs[3], H, nh)[0][:N].astype(np.float64)
-h0 = tiled_fp32(w0, offs[0], H, nh)[0][:N]
-err = np.abs(got0 - ref0)
-idx = np.argsort(err.reshape(-1))[::-1][:12]
-print("worst d pre_0 elements: row feature got ref h | row max")
-for i in idx:
-    r, f = divmod(int(i), H)
-    print("  %5d %4d % .6e % .6e % .5f | %.3e  (tile16 %d, n %d, group %d, b %d, kq %d, r %d)" %
-          (r, f, got0[r, f], ref0[r, f], h0[r, f], np.abs(ref0[r]).max(), r // 16, r % 16, f // 32, (f % 32) // 16, (f % 16) // 4, f % 4))
-rows = np.unique(idx // H)
-print("rows involved:", rows.tolist())
-relrow = err.max(axis=1) / (np.abs(ref0).max(axis=1) + 1e-300)
-print("rows with rel err > 1e-4:", int((relrow > 1e-4).sum()), "of", N, "; by n (row % 16):", np.bincount(np.where(relrow > 1e-4)[0] % 16, minlength=16).tolist())
-relf = err.max(axis=0) / (np.abs(ref0).max(axis=0) + 1e-300)
-print("features with rel err > 1e-4:", np.where(relf > 1e-4)[0].tolist()[:64])
 # ---- rows whose hidden d pre-activations are off: their du, dz and a few elements
 sizes2 = sizes + [t16 * (nh * (H // 32) + H // 64) * 64, t16 * 64, t16 * 64]
 offs2 = np.cumsum([0] + [al(s) for s in sizes2])
 du = f32(w2, offs2[7], t16 * 64)[:N]; dz = f32(w2, offs2[8], t16 * 64)[:N]
 refL = tiled_fp32(w0, offs[3], H, nh)
 gotL = packed(w2, offs[3], H, nh)[0]
-for l in range(nh - 1, 0, -1):
+for l in range(nh - 1, -1, -1):      # (layer 0 is packed like the others since round 3)
     r = refL[l][:N].astype(np.float64); g = gotL[l][:N]
     k = np.argmax(np.abs(r), axis=1); ratio = g[np.arange(N), k] / r[np.arange(N), k]
     scale = 2.0 ** np.round(np.log2(np.abs(ratio) + 1e-300))
