@@ -117,17 +117,36 @@ void launch_pack_x6(const pinn_net_t* net, const float* d_params, hipStream_t st
 
 // WAVES = 8: 128-row tiles, two waves per SIMD.  WAVES = 4 (small row counts, fewer tiles than CUs): 64-row tiles, one
 // wave per SIMD -- twice the CUs busy and no wave shares its SIMD's matrix core, so a tile finishes in about half the time.
-template <int H, bool MC, bool kBits, int WAVES>
+// MC-dropout moments: the passes are accumulated in TWO Welford states by parity (passes 0, 2, 4 .. and 1, 3, 5 ..) and merged
+// at the end (Chan's formula, one fixed order) -- in every variant, so that the results do not depend on which one ran.
+// kSplit (MC, 8 waves, row counts with at most one 64-row tile per CU -- the reference's own sizes): the two parities are two
+// WAVES.  A lone wave per SIMD issues a pass's MFMAs and its activation arithmetic in order (24.7 us per pass at 1.1e4 rows,
+// 46 % of the large-batch rate); passes are independent, so waves 4-7 run the odd passes of the rows whose even passes waves
+// 0-3 run, in step on the same weight stream, and the second wave of a SIMD fills the first one's gaps.
+struct Moments {
+  float mean, m2, sl;
+};
+__device__ __forceinline__ void merge_moments(Moments& a, const Moments& b, int n_passes) {      // a: even passes, b: odd passes
+  const float n0 = (float)((n_passes + 1) / 2), n1 = (float)(n_passes / 2), inv_n = 1.0f / (float)n_passes;
+  const float d = b.mean - a.mean;
+  a.mean = fmaf(d, n1 * inv_n, a.mean);
+  a.m2 = (a.m2 + b.m2) + (d * d) * (n0 * n1 * inv_n);
+  a.sl = a.sl + b.sl;
+}
+template <int H, bool MC, bool kBits, int WAVES, bool kSplit = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp_x6_kernel(FwdArgs a, const __bf16* packed) {
   using S = X3;                                   // forward passes: two fp16 parts, three products (pinn_x6_core.h)
-  constexpr int kThreadsX = WAVES * 64, kTileRowsX = WAVES * 16;
+  static_assert(!kSplit || (MC && WAVES == 8), "the pass split is an MC-dropout variant of the 8-wave kernel");
+  constexpr int kThreadsX = WAVES * 64, kTileRowsX = kSplit ? 64 : WAVES * 16;
   // one LDS block, small things FIRST: a ds instruction's immediate offset is 16 bits, and every per-layer bias /
   // head-weight address beyond 64 KB would need its own address register (hipcc hoists them all: spills)
   constexpr int kSmallBytes = kMaxSmall * 4, kW0Bytes = 8 * kW0Stride * 4;
-  constexpr int kSlabAt = (kSmallBytes + kW0Bytes + 1023) & ~1023;
+  constexpr int kMergeBytes = kSplit ? 4 * 16 * 3 * 4 : 0;      // the odd passes' moments of the tile's 64 rows
+  constexpr int kSlabAt = (kSmallBytes + kW0Bytes + kMergeBytes + 1023) & ~1023;
   __shared__ __attribute__((aligned(1024))) char smem[kSlabAt + 2 * S::Pipe::kSlab];
   float* small = reinterpret_cast<float*>(smem);
   float* w0t = reinterpret_cast<float*>(smem + kSmallBytes);
+  float* merge = reinterpret_cast<float*>(smem + kSmallBytes + kW0Bytes);
   char* lds_w = smem + kSlabAt;
   ParamLayout L{a.H, a.nh};
   PackLayout K{a.H, a.nh};
@@ -147,7 +166,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp_x6_kernel(FwdArgs a
   clock_stamp(0);
 #endif
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const long long lrow = tile * kTileRowsX + wave * kWaveRows + (lane & 15);
+    const int row_wave = kSplit ? (wave & 3) : wave, parity = kSplit ? (wave >> 2) : 0;
+    const long long lrow = tile * kTileRowsX + row_wave * kWaveRows + (lane & 15);
     const bool valid = lrow < a.n_rows;
     const long long srow = valid ? lrow : a.n_rows - 1;
     const long long grow = a.drop.row_offset + lrow;
@@ -163,26 +183,40 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mlp_x6_kernel(FwdArgs a
         a.o1[lrow] = logf(softplus_f32(z) + 1e-6f);
       }
     } else {
-      float u_eval = 0.f, mean = 0.f, m2 = 0.f, sl = 0.f;
+      float u_eval = 0.f;
+      Moments m_even{0.f, 0.f, 0.f}, m_odd{0.f, 0.f, 0.f};      // (kSplit: m_even = this wave's parity, m_odd = the other half's, handed over)
+      // kSplit: this wave runs the eval pass and the passes of its parity -- ceil(T / 2) of them in BOTH halves of the workgroup (the
+      // slab barriers count every wave): the odd half's last one is a spare when T is odd, computed and dropped
+      const int t_step = kSplit ? 2 : 1, t_end = kSplit ? 2 * ((a.n_passes + 1) / 2) : a.n_passes;
 #pragma unroll 1
-      for (int t = -1; t < a.n_passes; ++t) {
+      for (int t = -1; t < t_end; t = t < 0 ? parity : t + t_step) {
+        const bool spare = t >= a.n_passes;
         c.mode = (t < 0) ? PINN_DROP_NONE : a.drop.mode;
-        c.pass = (unsigned)(t < 0 ? 0 : t);
+        c.pass = (unsigned)(t < 0 || spare ? 0 : t);
         float u, z;
         PINN_STAMP(pipe, 3);
         forward_pass<S, H, kBits, false, WAVES>(w0t, small, L, pipe, a.drop, c, xa, xb, u, z);
         if (t < 0) {
           u_eval = u;
-        } else {
-          welford_update(mean, m2, u - u_eval, 1.0f / (float)(t + 1));      // population variance of the passes: m2 / T
-          sl += logf(softplus_f32(z) + 1e-6f);
+        } else if (!spare) {
+          const float inv_k = 1.0f / (float)(t / 2 + 1), lv = logf(softplus_f32(z) + 1e-6f);      // k-th pass of its parity
+          if (kSplit || !(t & 1)) { welford_update(m_even.mean, m_even.m2, u - u_eval, inv_k); m_even.sl += lv; }
+          else { welford_update(m_odd.mean, m_odd.m2, u - u_eval, inv_k); m_odd.sl += lv; }
         }
       }
-      if (valid && lane < 16) {
+      if constexpr (kSplit) {        // the odd half hands its moments over
+        float* slot = merge + (row_wave * 16 + (lane & 15)) * 3;
+        if (parity == 1 && lane < 16) { slot[0] = m_even.mean; slot[1] = m_even.m2; slot[2] = m_even.sl; }
+        __syncthreads();
+        if (parity == 0) { m_odd.mean = slot[0]; m_odd.m2 = slot[1]; m_odd.sl = slot[2]; }
+        __syncthreads();             // (the next tile's hand-over must not overtake this read)
+      }
+      if (valid && lane < 16 && parity == 0) {
+        merge_moments(m_even, m_odd, a.n_passes);
         const float inv_t = 1.0f / (float)a.n_passes;
-        const float var = m2 * inv_t;
+        const float var = m_even.m2 * inv_t;                     // population variance of the passes
         a.o0[lrow] = u_eval;
-        a.o1[lrow] = expf(0.5f * (sl * inv_t));
+        a.o1[lrow] = expf(0.5f * (m_even.sl * inv_t));
         a.o2[lrow] = sqrtf(var);
       }
     }
@@ -217,7 +251,8 @@ int launch_forward_x6(const pinn_net_t* net, const FwdArgs& a, bool mc, void* st
   const bool bits = a.drop.mode == PINN_DROP_BITS;
 #define PINN_LAUNCH_X(HH, MCC, BB)                                                                                              \
   do {                                                                                                                          \
-    if (small_n) hipLaunchKernelGGL((mlp_x6_kernel<HH, MCC, BB, 4>), dim3(grid), dim3(256), 0, st, a, packed);                  \
+    if (small_n && MCC) hipLaunchKernelGGL((mlp_x6_kernel<HH, MCC, BB, 8, MCC>), dim3(grid), dim3(512), 0, st, a, packed);      \
+    else if (small_n) hipLaunchKernelGGL((mlp_x6_kernel<HH, MCC, BB, 4>), dim3(grid), dim3(256), 0, st, a, packed);             \
     else hipLaunchKernelGGL((mlp_x6_kernel<HH, MCC, BB, 8>), dim3(grid), dim3(512), 0, st, a, packed);                          \
   } while (0)
   if (net->hidden == 256) {
