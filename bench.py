@@ -187,8 +187,9 @@ def leg_config1(with_cpu):
     m.train_dnn(2); pinn_amd.get_MC_samples(m, ds[2][:256], ds[4], mc_times=2, dropout=0.4); torch.cuda.synchronize()     # warm-up
     t0 = time.perf_counter(); m.train_dnn(100); torch.cuda.synchronize(); t_train = time.perf_counter() - t0
     t0 = time.perf_counter(); pinn_amd.get_MC_samples(m, ds[2], ds[4], mc_times=32, dropout=0.4); t_mc = time.perf_counter() - t0
-    # the reference's real call is train_dnn(4001) / (8001): 2000 steps of the same call show the replayed-graph rate without the
-    # one-off capture (a few ms, a tenth of a 100-step call), next to the launch-by-launch path
+    # the reference's real call is train_dnn(4001) / (8001): 2000 steps of the same call as a replayed hipGraph (opt-in: a replayed
+    # step is a few us slower than a launched one on this runtime), next to the default launch-by-launch path
+    m.use_graph = True
     t0 = time.perf_counter(); m.train_dnn(2000); torch.cuda.synchronize(); t_long = time.perf_counter() - t0
     m.use_graph = False
     t0 = time.perf_counter(); m.train_dnn(500); torch.cuda.synchronize(); t_eager = time.perf_counter() - t0

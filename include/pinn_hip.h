@@ -280,6 +280,12 @@ int pinn_mlp_train_step_dev(const pinn_net_t* net, float* d_params, const float*
                             long long n_rows, long long n_global, const pinn_dropout_t* drop, float* d_grads,
                             double* d_loss, void* d_work, size_t work_bytes, float* d_m, float* d_v,
                             const float* d_coeffs, void* stream);
+/* The same with the step's two scalars by value (pinn_adam_step's lr and 1-based step): pinn_mlp_train_grads + pinn_adam_step
+ * as one launch sequence for callers that launch step by step.  Bit-identical to the two calls.  Every precision and width. */
+int pinn_mlp_train_step(const pinn_net_t* net, float* d_params, const float* d_x, const float* d_y,
+                        long long n_rows, long long n_global, const pinn_dropout_t* drop, float* d_grads,
+                        double* d_loss, void* d_work, size_t work_bytes, float* d_m, float* d_v, float lr, int step,
+                        void* stream);
 
 /* ---- results assembly: create_comprehensive_results_array_v2 (01:1877-2010) -----------------------------------
  * Fills d_out = float64 [n_rows, 22] row-major (the `comprehensive_results` layout scripts 02-05 read):

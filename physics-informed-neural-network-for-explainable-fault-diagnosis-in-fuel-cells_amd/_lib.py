@@ -88,6 +88,8 @@ _SIGS = {
     "pinn_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p]),
     "pinn_mlp_train_step_dev": (c_int, [ctypes.POINTER(Net), c_void_p, c_void_p, c_void_p, c_ll, c_ll, ctypes.POINTER(Dropout),
                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pinn_mlp_train_step": (c_int, [ctypes.POINTER(Net), c_void_p, c_void_p, c_void_p, c_ll, c_ll, ctypes.POINTER(Dropout),
+                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "pinn_residuals_prepare": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(Affine), c_void_p, c_uint, c_ll, c_void_p, c_void_p]),
     "pinn_residuals_cached": (c_int, [c_void_p, ctypes.POINTER(Affine), c_void_p, c_uint, c_ll, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pinn_net_f_t": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Affine), c_void_p, c_ll, c_void_p, c_void_p, c_void_p,

@@ -427,7 +427,8 @@ constexpr int kFinLanes = 8, kFinGroups = 32;
 // counter as the forward kernel of this call read it (TrainBuffers::amax + 2): the counter itself moves during this launch.
 struct FinAdam {
   float* p; float* m; float* v;
-  const float* coeffs; const unsigned* snap;
+  const float* coeffs; const unsigned* snap;      // device table + step snapshot (pinn_mlp_train_step_dev), or nullptr:
+  float step_size, bc2_sqrt;                      // the step's two scalars by value (pinn_mlp_train_step)
 };
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f64x4 widen4(const f32x4& v) { return f64x4{(double)v[0], (double)v[1], (double)v[2], (double)v[3]}; }
@@ -448,8 +449,12 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
   if (with_loss && step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1u;
   float step_size = 0.0f, bc2_sqrt = 1.0f;
   if (ad.p) {
-    const unsigned k = __builtin_amdgcn_readfirstlane(*ad.snap);
-    step_size = ad.coeffs[2 * k]; bc2_sqrt = ad.coeffs[2 * k + 1];
+    if (ad.coeffs) {
+      const unsigned k = __builtin_amdgcn_readfirstlane(*ad.snap);
+      step_size = ad.coeffs[2 * k]; bc2_sqrt = ad.coeffs[2 * k + 1];
+    } else {
+      step_size = ad.step_size; bc2_sqrt = ad.bc2_sqrt;
+    }
   }
   const int g = threadIdx.x & (kFinGroups - 1), q = threadIdx.x / kFinGroups;
   // every tensor starts on a multiple of 4 floats, so the two scalar head biases sit at the start of a group whose other
@@ -697,7 +702,7 @@ static int train_grads_impl(const pinn_net_t* net, const float* d_params, const 
   const int H = net->hidden, nh = net->n_hidden;
   ParamLayout L{H, nh};
   FinAdam fin_adam{};
-  if (fa) { fin_adam = *fa; fin_adam.snap = (const unsigned*)(base + w.off_amax) + 2; }
+  if (fa) { fin_adam = *fa; fin_adam.snap = fa->coeffs ? (const unsigned*)(base + w.off_amax) + 2 : nullptr; }
 
   TrainArgs a{};
   a.params = d_params; a.x = d_x; a.y = d_y; a.n_rows = n_rows; a.n_global = n_global; a.H = H; a.nh = nh;
@@ -747,7 +752,7 @@ static int train_grads_impl(const pinn_net_t* net, const float* d_params, const 
     if (phases & PINN_PHASE_REDUCE)
       hipLaunchKernelGGL(grad_finalize_kernel, dim3((unsigned)((L.total() / 4 + kFinGroups - 1) / kFinGroups)), dim3(256), 0, st, b.slabs, w.n_slices,
                          L.total(), a.loss_part, grid, L.bp(), L.bv2(), d_grads, d_loss, (const unsigned*)nullptr, (unsigned*)nullptr, a.drop.step_counter,
-                         0LL, (long long)L.total(), 1, FinAdam{});
+                         0LL, (long long)L.total(), 1, fin_adam);
     hipError_t eb = hipGetLastError();
     return eb == hipSuccess ? PINN_OK : (int)eb;
   }
@@ -908,7 +913,21 @@ extern "C" int pinn_mlp_train_step_dev(const pinn_net_t* net, float* d_params, c
   if (!net || !drop || !drop->d_step_counter || !d_m || !d_v || !d_coeffs) return PINN_E_ARG;
   if (!(net->precision >= PINN_PREC_F32X6 && net->hidden <= 256)) return PINN_E_ARCH;      // (the kernels that leave the counter's snapshot)
   if (((unsigned long long)d_params | (unsigned long long)d_m | (unsigned long long)d_v) & 15) return PINN_E_ARG;
-  const FinAdam fa{d_params, d_m, d_v, d_coeffs, nullptr};
+  const FinAdam fa{d_params, d_m, d_v, d_coeffs, nullptr, 0.0f, 1.0f};
+  return train_grads_impl(net, d_params, d_x, d_y, n_rows, n_global, drop, d_grads, d_loss, d_work, work_bytes, stream, PINN_PHASE_ALL, &fa);
+}
+
+// The same with the step's scalars by value (lr from StepLR, step 1-based: pinn_adam_step's arguments): pinn_mlp_train_grads +
+// pinn_adam_step in one launch sequence, for callers that launch step by step.  Every precision and width.
+extern "C" void pinn_adam_coeffs(float lr, int step, float* step_size, float* bc2_sqrt);
+extern "C" int pinn_mlp_train_step(const pinn_net_t* net, float* d_params, const float* d_x, const float* d_y,
+                                   long long n_rows, long long n_global, const pinn_dropout_t* drop, float* d_grads,
+                                   double* d_loss, void* d_work, size_t work_bytes, float* d_m, float* d_v, float lr, int step,
+                                   void* stream) {
+  if (!net || !d_m || !d_v || step < 1) return PINN_E_ARG;
+  if (((unsigned long long)d_params | (unsigned long long)d_m | (unsigned long long)d_v) & 15) return PINN_E_ARG;
+  FinAdam fa{d_params, d_m, d_v, nullptr, nullptr, 0.0f, 1.0f};
+  pinn_adam_coeffs(lr, step, &fa.step_size, &fa.bc2_sqrt);
   return train_grads_impl(net, d_params, d_x, d_y, n_rows, n_global, drop, d_grads, d_loss, d_work, work_bytes, stream, PINN_PHASE_ALL, &fa);
 }
 

@@ -353,7 +353,7 @@ class PhysicsInformedNN():
             self._work[key] = torch.empty(wb, dtype=torch.uint8, device=self.x.device)
         return self._work[key]
 
-    def train_step_grads(self, x, y, row_offset, n_global, between=None):
+    def train_step_grads(self, x, y, row_offset, n_global, between=None, adam=None):
         """One fused forward + aleatoric_loss + backward on rows (x, y): fills the flat gradient
         (already divided by n_global) and returns the raw loss sums double[4] on the device.
         `between` (data-parallel overlap): called once the TAIL of the gradient -- last hidden layer and heads,
@@ -372,7 +372,12 @@ class PhysicsInformedNN():
                                                        int(n_global), ctypes.byref(drop) if drop else None,
                                                        _ptr(self.dnn._flat_grad), _ptr(loss), _ptr(work), work.numel(), _stream(), phases)
             _lib.check(rc, "pinn_mlp_train_grads")
-        if between is None:
+        if adam is not None:      # (lr, step): the optimizer step rides in the gradient reduction's launch (single process, no collective in between)
+            rc = self._lib.pinn_mlp_train_step(ctypes.byref(self.dnn._net), _ptr(self.dnn.flat_params()), _ptr(x), _ptr(y), n, int(n_global),
+                                               ctypes.byref(drop) if drop else None, _ptr(self.dnn._flat_grad), _ptr(loss), _ptr(work),
+                                               work.numel(), _ptr(self._adam_m), _ptr(self._adam_v), adam[0], adam[1], _stream())
+            _lib.check(rc, "pinn_mlp_train_step")
+        elif between is None:
             run(_lib.PHASE_ALL)
         else:
             run(_lib.PHASE_CHAIN | _lib.PHASE_WGRAD_TAIL | _lib.PHASE_REDUCE_TAIL)
@@ -421,12 +426,14 @@ class PhysicsInformedNN():
                 w.wait()              # the current stream waits for the collective (NCCL); gloo: the host does
         return loss
 
-    # train_dnn at the reference's data sizes (1e3-1e4 rows, 12 002 steps: 01:2143-2147) is launch-bound: ten dependent launches
-    # per step.  With one process and full batches the step is captured ONCE as a hipGraph and replayed: step count, Adam
-    # coefficients and dropout stream live on the device (pinn_dropout_t.d_step_counter, pinn_adam_step_dev), so nothing
+    # train_dnn at the reference's data sizes (1e3-1e4 rows, 12 002 steps: 01:2143-2147) is a chain of short dependent launches
+    # (five per step).  With one process and full batches the step can be captured ONCE as a hipGraph and replayed: step count,
+    # Adam coefficients and dropout stream live on the device (pinn_dropout_t.d_step_counter, pinn_mlp_train_step_dev), so nothing
     # in the captured sequence changes from step to step.  Same kernels, same arguments otherwise: bit-identical to the
-    # launch-by-launch path (tests/test_gpu_model.py); use_graph = False forces that path.
-    use_graph = True
+    # launch-by-launch path (tests/test_gpu_model.py).  Opt-in: since the step's launches all sit on one stream, a replayed
+    # step is 3-8 us SLOWER than a launched one on this runtime (92-103 against 87-95 us at 500 .. 4200 rows); what the graph
+    # buys is a free host thread.
+    use_graph = False
 
     def _train_dnn_replay(self, epochs, x, y, n_norm, log):
         """Steps 2 .. epochs of a full-batch train_dnn call as replays of one captured step (step 1 ran launch by launch:
@@ -525,8 +532,11 @@ class PhysicsInformedNN():
             lr = 0.01 * 0.8 ** (epoch // 1000)
             for (s, e, n_norm) in batches:
                 xb, yb = (x, y) if (s, e) == (0, n) else (x[s:e], y[s:e])
-                loss_sums = self._dp_step(xb, yb, self.row_offset + s, n_norm, e > s)
                 step += 1
+                if self.fuse_adam and not _dp._active(self._group) and e > s:      # one process: gradients and Adam in one launch sequence
+                    loss_sums = self.train_step_grads(xb, yb, self.row_offset + s, n_norm, adam=(lr, step))
+                    continue
+                loss_sums = self._dp_step(xb, yb, self.row_offset + s, n_norm, e > s)
                 rc = self._lib.pinn_adam_step(_ptr(flat), _ptr(grad), _ptr(self._adam_m), _ptr(self._adam_v), flat.numel(),
                                               lr, step, _stream())
                 _lib.check(rc, "pinn_adam_step")
@@ -595,6 +605,7 @@ class PhysicsInformedNN():
         self.last_loss = float(loss[0].item()) if nIter > 0 else None
 
     graph_chunk = 8                 # train_dnn steps per graph launch in long replayed calls
+    fuse_adam = True                # single process: the Adam step rides in the gradient reduction's launch (False: two calls, bit-identical)
     graph_min_steps = 200           # shorter calls launch their steps one by one: a capture costs ~0.5 ms, a replayed step is no faster
     stage_run_max_rows = 32768      # <= _lib.STAGE_RUN_MAX_ROWS; larger series iterate the multi-workgroup kernels
     _lambda_log_view = None

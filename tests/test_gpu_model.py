@@ -109,7 +109,7 @@ def test_train_dnn_three_steps_golden():
     m = _model_from_golden(g, g["x"], g["y"], sx, sy, prefix="w0.")
     per_step = [[unpack_mask(g["mask%d_s%d" % (l, s)], 128 if l < 3 else 64) for l in range(4)] for s in range(3)]
     m.dnn.inject_masks(hh.pack_mask_bits(per_step))
-    m.graph_min_steps = 0              # through the replayed-graph path (the default only for calls of >= 200 steps)
+    m.use_graph, m.graph_min_steps = True, 0      # through the replayed-graph path (opt-in, and by default only for calls of >= 200 steps)
     m.train_dnn(3)
     sd = m.dnn.state_dict()
     for n in O.param_names(3):
@@ -310,7 +310,7 @@ def test_train_dnn_philox_masks_vs_oracle(batch_size):
     names = O.param_names(3)
     sd = m.dnn.state_dict()
     P = [sd[n].detach().cpu().clone() for n in names]
-    m.graph_min_steps = 0              # the full-batch case runs through the replayed graph
+    m.use_graph, m.graph_min_steps = True, 0      # the full-batch case runs through the replayed graph
     m.train_dnn(epochs, batch_size=batch_size)
     bounds = [(0, N)] if batch_size is None else [(s, min(N, s + batch_size)) for s in range(0, N, batch_size)]
     mask_fn = lambda step, s, e: (O.philox_masks_for_net(seed, step, s, e - s, H, 3, [0.2] * 4), [0.2] * 4)
@@ -359,6 +359,29 @@ def test_train_dnn_graph_replay_is_bit_identical(precision, H):
         for k, (a, b) in enumerate(zip(eager, graph)):
             assert (torch.equal(a, b) if torch.is_tensor(a) else a == b), ("element %d differs" % k, precision, bits is not None)
         assert torch.isfinite(eager[0]).all() and eager[4] == steps
+
+
+@pytest.mark.parametrize("precision,H", [("f32x6", 256), ("fp32", 128), ("bf16", 128), ("f32x6", 512)])
+def test_train_step_with_adam_in_the_reduction_is_bit_identical(precision, H):
+    """pinn_mlp_train_step (gradients + Adam as one launch sequence, the default of a single-process train_dnn) against
+    pinn_mlp_train_grads followed by pinn_adam_step: same weights, moments and loss, bit for bit, full batch and minibatches."""
+    import pinn_amd
+    from pinn_amd import synth
+    ds = synth.make_dataset(500, (), seed=23)
+
+    def run(fuse, batch_size):
+        torch.manual_seed(7)
+        m = pinn_amd.PhysicsInformedNN(ds[0], ds[1], [8, H, H, 1], ds[4], ds[5], p=0.2, logvar=True, seed=5, precision=precision)
+        m.verbose = False
+        m.use_graph = False
+        m.fuse_adam = fuse
+        m.train_dnn(4, batch_size=batch_size)
+        return m.dnn.flat_params().clone(), m._adam_m.clone(), m._adam_v.clone(), m.last_loss
+    for bs in (None, 200):
+        a, b = run(True, bs), run(False, bs)
+        for k, (u, v) in enumerate(zip(a, b)):
+            assert (torch.equal(u, v) if torch.is_tensor(u) else u == v), ("element %d differs" % k, precision, bs)
+        assert torch.isfinite(a[0]).all()
 
 
 def test_reference_main_flow(tmp_path):
