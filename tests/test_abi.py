@@ -100,6 +100,17 @@ def test_null_workspace_and_buffer_pointers_are_argument_errors(lib):
     d.mode = _lib.DROP_BITS            # injected masks without the mask buffer
     assert lib.pinn_mlp_forward(ctypes.byref(net), one, one, 10, ctypes.byref(d), one, one, None) == E_ARG
     assert lib.pinn_adam_step(one, one, None, one, 10, 0.01, 1, None) == E_ARG
+    # gradients + Adam as one launch sequence: NULL moments / coefficient table / step counter, a step count below 1, and the
+    # device-counter form on a precision whose kernels do not leave the counter's snapshot
+    al = ctypes.c_void_p(0x1000)
+    assert lib.pinn_mlp_train_step(ctypes.byref(net), al, one, one, 10, 10, None, al, one, ctypes.c_void_p(0x2000), 1 << 30, None, al, 0.01, 1, None) == E_ARG
+    assert lib.pinn_mlp_train_step(ctypes.byref(net), al, one, one, 10, 10, None, al, one, ctypes.c_void_p(0x2000), 1 << 30, al, al, 0.01, 0, None) == E_ARG
+    assert lib.pinn_mlp_train_step(ctypes.byref(net), al, one, one, 10, 10, None, al, one, None, 1 << 30, al, al, 0.01, 1, None) == E_ARG
+    dc = _lib.Dropout(); dc.mode = _lib.DROP_PHILOX
+    assert lib.pinn_mlp_train_step_dev(ctypes.byref(net), al, one, one, 10, 10, ctypes.byref(dc), al, one, ctypes.c_void_p(0x2000), 1 << 30, al, al, al, None) == E_ARG  # no counter
+    dc.d_step_counter = 0x3000
+    assert lib.pinn_mlp_train_step_dev(ctypes.byref(net), al, one, one, 10, 10, ctypes.byref(dc), al, one, ctypes.c_void_p(0x2000), 1 << 30, al, al, None, None) == E_ARG
+    assert lib.pinn_mlp_train_step_dev(ctypes.byref(net), al, one, one, 10, 10, ctypes.byref(dc), al, one, ctypes.c_void_p(0x2000), 1 << 30, al, al, al, None) == -2     # PINN_E_ARCH: exact fp32
     assert lib.pinn_results_assemble(one, one, ctypes.byref(aff), 0.0, 1.0, 200, None, 0, one, one, one, one, 10, None, 10, None, None) == E_ARG
 
 
