@@ -581,7 +581,15 @@ static Workspace plan_workspace(const pinn_net_t* net, long long n_rows) {
 #else
   constexpr long long kMultiSlices = 32;
 #endif
-  const long long cap = w.t16 < kFanOutT16 ? (one_launch ? kMultiSlices : 64) : kMaxSlices;
+  // wide nets: a gradient is (H / 256)^2 blocks of 256 x 256, each with its own slices -- two rounds of workgroups fill the chip, and
+  // every further slice is a slab of the whole gradient written and read back (H = 1024 at 262 144 rows: 256 slices wrote 1.07 GB per
+  // layer, profiles/r03/pmc_summary_wide.json; 32 slices: training step 21.05 -> 19.6 ms; 16: 20.4; 8: 25.6)
+#ifdef PINN_ABL_WIDE_NS
+  const long long wide_slices = PINN_ABL_WIDE_NS;
+#else
+  const long long hb = H / 256, wide_slices = hb > 0 && 512 / (hb * hb) > 8 ? 512 / (hb * hb) : 8;
+#endif
+  const long long cap = w.t16 < kFanOutT16 ? (one_launch ? kMultiSlices : 64) : (H > 256 ? wide_slices : (long long)kMaxSlices);
   w.n_slices = (int)(t32 < cap ? (t32 < 1 ? 1 : t32) : cap);
   ParamLayout L{(int)H, (int)nh};
   w.off_slabs = take((size_t)w.n_slices * L.total() * 4);
