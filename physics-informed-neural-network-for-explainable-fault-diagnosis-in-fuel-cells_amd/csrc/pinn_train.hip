@@ -520,6 +520,16 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const float* __restr
 }
 
 constexpr long long kFanOutT16 = 2048;       // row tiles below which the weight-gradient launches fan out over side streams
+// Row tiles below which PINN_PREC_F32X6 at H = 256 runs every layer's weight gradient as ONE launch of 128 x 128 tiles over 32
+// slices (wgrad_p_multi_kernel).  Built for the reference's 1e3 .. 1e4 rows, it wins far beyond: five launches of 256 slices
+// write and read back 180 MB of slabs whatever the row count -- at BASELINE config 4's 65 536-row minibatch that was as much
+// traffic as the operands themselves (weight gradients 164 -> 123 us, reduction 31 -> 6 us, step 441 -> 372 us; 131 072 rows:
+// 770 -> 740; 262 144: 1356 vs 1420, the per-layer kernels' 256 x 256 tiles win from there).
+#ifdef PINN_ABL_MULTI_T16
+constexpr long long kMultiT16 = PINN_ABL_MULTI_T16;
+#else
+constexpr long long kMultiT16 = 10240;
+#endif
 
 // Side streams for the independent weight-gradient launches of one step at small row counts.  Fork / join with events on the
 // caller's stream, so the pattern is legal inside a stream capture (model.train_dnn replays the step as a hipGraph, where the
@@ -589,7 +599,7 @@ static Workspace plan_workspace(const pinn_net_t* net, long long n_rows) {
 #else
   const long long hb = H / 256, wide_slices = hb > 0 && 512 / (hb * hb) > 8 ? 512 / (hb * hb) : 8;
 #endif
-  const long long cap = w.t16 < kFanOutT16 ? (one_launch ? kMultiSlices : 64) : (H > 256 ? wide_slices : (long long)kMaxSlices);
+  const long long cap = (one_launch && w.t16 < kMultiT16) ? kMultiSlices : (w.t16 < kFanOutT16 ? 64 : (H > 256 ? wide_slices : (long long)kMaxSlices));
   w.n_slices = (int)(t32 < cap ? (t32 < 1 ? 1 : t32) : cap);
   ParamLayout L{(int)H, (int)nh};
   w.off_slabs = take((size_t)w.n_slices * L.total() * 4);
@@ -804,7 +814,7 @@ static int train_grads_impl(const pinn_net_t* net, const float* d_params, const 
     const bool do_tail = phases & PINN_PHASE_WGRAD_TAIL, do_head = phases & PINN_PHASE_WGRAD_HEAD;
     auto in_part = [&](int l) { return l == nh - 1 ? do_tail : do_head; };      // hidden layer l >= 1
     // small row counts: the launches of the layers are independent and short -- side by side on up to four streams
-    const bool multi = w.t16 < kFanOutT16 && net->precision == PINN_PREC_F32X6 && H == 256 && nh - 1 + 3 <= kMaxWgradProblems;
+    const bool multi = w.t16 < kMultiT16 && net->precision == PINN_PREC_F32X6 && H == 256 && nh - 1 + 3 <= kMaxWgradProblems;
     const bool fan = !multi && w.t16 < kFanOutT16 && g_fan.init();
     int n_launch = 0;
     bool used[3] = {false, false, false};
