@@ -77,6 +77,22 @@ def _rccl_worker(port, q):
         want_s = sums.clone()
         dp.allreduce_sums(sums, None, force=True)
         torch.cuda.synchronize()
+        # the two-part form of model._dp_step on RCCL itself: the tail's collective started asynchronously on a side stream
+        # behind an event, the head's on the compute stream, both waited for before the bucket is read
+        import ctypes
+        split = int(m._lib.pinn_grad_split(ctypes.byref(m.dnn._net)))
+        assert 0 < split < bucket.numel()
+        side = torch.cuda.Stream(device=bucket.device)
+        ev = torch.cuda.Event(); ev.record()
+        works = []
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            works.append(dp.allreduce_grads_begin(bucket[split:], None, force=True))
+        works.append(dp.allreduce_grads_begin(bucket[:split], None, force=True))
+        for w in works:
+            assert w is not None
+            w.wait()
+        torch.cuda.synchronize()
         q.put(("ok", dp.backend(), bool(torch.equal(bucket, want)), bool(torch.equal(sums, want_s)), float(want.abs().sum().item())))
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001 -- reported to the parent, which fails the test
